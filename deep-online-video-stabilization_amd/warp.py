@@ -1,0 +1,92 @@
+"""Host mirror of the reference's warp operators over the C ABI (same names, argument meaning, returns).
+
+  transformer(U, theta)            spatial_transformer3.py:19   -> (output, black_pix, img)
+  interpolate(im, x, y, out_size)  spatial_transformer.py:200   -> output
+  get_4_pts(theta, batch_size)     s_net_bundle_nobm.py:29      -> (pts1, pts2)
+
+Tensors are torch CUDA(HIP) float32, NHWC.  No CPU fallback."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._tensor import dev_f32, empty, ptr, stream_ptr
+from .config import Config, v2_93
+
+
+def get_4_pts(theta: torch.Tensor, batch_size=None, cfg: Config = v2_93, with_Hs: bool = False):
+    theta = dev_f32(theta, "theta")
+    N = theta.shape[0]
+    gh, gw = cfg.grid_h, cfg.grid_w
+    assert theta.shape[1] == (gh + 1) * (gw + 1) * 2
+    pts2 = empty((N, gh + 1, gw + 1, 2), theta)
+    Hs = empty((N, gh, gw, 9), theta)
+    _lib.call("stabnet_get_4_pts", ptr(theta), N, gh, gw, cfg.do_crop_rate, ptr(pts2), ptr(Hs), stream_ptr())
+    # pts1: per cell [xTL,xTR,xBL,xBR,yTL,yTR,yBL,yBR] (s_net_bundle_nobm.py:65-66) -- a re-packing of pts2
+    tl, tr = pts2[:, :-1, :-1], pts2[:, :-1, 1:]
+    bl, br = pts2[:, 1:, :-1], pts2[:, 1:, 1:]
+    pts1 = torch.stack([tl, tr, bl, br], dim=-1).reshape(N, gh, gw, 8)
+    if with_Hs:
+        return pts1, pts2, Hs
+    return pts1, pts2
+
+
+def transformer(U: torch.Tensor, theta: torch.Tensor, name="SpatialTransformer", cfg: Config = v2_93,
+                return_Hs: bool = False):
+    """U [N,H,W,C]; theta = pts2 [N,gh+1,gw+1,2] -> (output [N,H,W,C], black_pix [N,H,W], img [N,H,W,2])."""
+    U = dev_f32(U, "U")
+    pts2 = dev_f32(theta, "theta")
+    N, H, W, C = U.shape
+    out = empty((N, H, W, C), U)
+    black = empty((N, H, W), U)
+    xm = empty((N, H, W), U)
+    ym = empty((N, H, W), U)
+    Hs = empty((N, cfg.grid_h, cfg.grid_w, 9), U)
+    _lib.call("stabnet_transformer_fwd", ptr(pts2), ptr(U), N, H, W, C, cfg.grid_h, cfg.grid_w, ptr(out), ptr(black),
+              ptr(xm), ptr(ym), ptr(Hs), stream_ptr())
+    img = torch.stack([xm, ym], dim=3)
+    if return_Hs:
+        return out, black, img, Hs
+    return out, black, img
+
+
+def warp_from_theta(U: torch.Tensor, theta: torch.Tensor, cfg: Config = v2_93):
+    """Fused get_4_pts + transformer on the raw regressor output theta [N,50].
+    -> dict(output, black_pix, x_map, y_map, Hs, pts2) with the deploy tensor shapes (deploy_bundle.py:48-56)."""
+    U = dev_f32(U, "U")
+    theta = dev_f32(theta, "theta")
+    N, H, W, C = U.shape
+    out = empty((N, H, W, C), U)
+    black = empty((N, H, W), U)
+    xm = empty((N, H, W, 1), U)
+    ym = empty((N, H, W, 1), U)
+    Hs = empty((N, cfg.grid_h, cfg.grid_w, 9), U)
+    pts2 = empty((N, cfg.grid_h + 1, cfg.grid_w + 1, 2), U)
+    _lib.call("stabnet_warp_fwd", ptr(theta), ptr(U), N, H, W, C, cfg.grid_h, cfg.grid_w, cfg.do_crop_rate, ptr(out),
+              ptr(black), ptr(xm), ptr(ym), ptr(Hs), ptr(pts2), stream_ptr())
+    return {"output": out, "black_pix": black, "x_map": xm, "y_map": ym, "Hs": Hs, "pts2": pts2}
+
+
+def maps_from_Hs(U: torch.Tensor, Hs: torch.Tensor, cfg: Config = v2_93):
+    U = dev_f32(U, "U")
+    Hs = dev_f32(Hs, "Hs")
+    N, H, W, C = U.shape
+    out = empty((N, H, W, C), U)
+    black = empty((N, H, W), U)
+    xm = empty((N, H, W), U)
+    ym = empty((N, H, W), U)
+    _lib.call("stabnet_maps_from_hs_fwd", ptr(Hs), ptr(U), N, H, W, C, cfg.grid_h, cfg.grid_w, ptr(out), ptr(black),
+              ptr(xm), ptr(ym), stream_ptr())
+    return out, black, xm, ym
+
+
+def interpolate(im: torch.Tensor, x: torch.Tensor, y: torch.Tensor, out_size=None, name="SpatialInterpolate"):
+    """im [N,H,W,C]; x,y [N,H,W,1] (or [N,H,W]) normalised coords -> [N,H,W,C]."""
+    im = dev_f32(im, "im")
+    x = dev_f32(x, "x")
+    y = dev_f32(y, "y")
+    N, H, W, C = im.shape
+    assert x.numel() == N * H * W and y.numel() == N * H * W
+    out = empty((N, H, W, C), im)
+    _lib.call("stabnet_interp_fwd", ptr(im), ptr(x), ptr(y), N, H, W, C, ptr(out), stream_ptr())
+    return out

@@ -1,0 +1,63 @@
+/* libstabnet_hip.so -- C ABI of the MI355X (gfx950) StabNet hot path.
+ *
+ * The reference (cxjyxxme/deep-online-video-stabilization, TensorFlow 1.3) has no FFI: its boundary is the
+ * TF1 session -- Python op signatures at graph-build time plus a named-tensor contract at run time
+ * (SURVEY.md section 8b).  Each entry point below replaces the TF-op cluster behind one of those Python
+ * signatures / fetched tensors; the citation names it (file:line in the reference tree).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers to CALLER-OWNED DEVICE memory, NHWC contiguous float32 unless stated; explicit shapes;
+ *     `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - never allocates, frees or synchronises; work that needs scratch takes a caller-provided workspace whose
+ *     size is queried up front; every call only enqueues kernels on `stream` (hipGraph-capturable);
+ *   - returns 0 on success, negative on error (-1 bad argument, -2 launch failure, -3 workspace too small);
+ *     the message is available from stabnet_last_error() (thread-local);
+ *   - thread-safe per stream.
+ */
+#ifndef STABNET_HIP_H
+#define STABNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* stabnet_last_error(void);
+int stabnet_abi_version(void);
+
+/* ---- mesh + multi-grid warp, forward ------------------------------------------------------------------- */
+
+/* get_4_pts(theta, batch_size) -> pts2            s_net_bundle_nobm.py:29-71
+ * + get_Hs(pts2) -> Hs                           spatial_transformer3.py:179-198 (get_H/pinv :144-175)
+ * theta [N,(gh+1)(gw+1)*2] -> pts2 [N,gh+1,gw+1,2] (vertex = regular grid + offset, clipped to +-1/do_crop_rate),
+ * Hs [N,gh,gw,9] (h = inv(A + 1e-4 I) b, last entry 1).  pts1 is a re-packing of pts2 done by the host mirror. */
+int stabnet_get_4_pts(const float* theta, int N, int grid_h, int grid_w, float do_crop_rate,
+                      float* pts2, float* Hs, void* stream);
+
+/* transformer(U, theta=pts2) -> (output, black_pix, img=[x_map,y_map])   spatial_transformer3.py:19,218-301,362-365
+ * Fetched in deploy as output_img:0, black_pix:0, get_Hs/Hs:0, x_map:0, y_map:0 (deploy_bundle.py:48-56,286).
+ * U [N,H,W,C]; pts2 [N,gh+1,gw+1,2]; out [N,H,W,C]; black,x_map,y_map [N,H,W]; Hs [N,gh,gw,9]. */
+int stabnet_transformer_fwd(const float* pts2, const float* U, int N, int H, int W, int C, int grid_h, int grid_w,
+                            float* out, float* black, float* x_map, float* y_map, float* Hs, void* stream);
+
+/* Fused get_4_pts + transformer: what one deploy frame / training tower runs after the regressor
+ * (s_net_bundle_nobm.py:304-307,332).  pts2 may be NULL. */
+int stabnet_warp_fwd(const float* theta, const float* U, int N, int H, int W, int C, int grid_h, int grid_w,
+                     float do_crop_rate, float* out, float* black, float* x_map, float* y_map, float* Hs,
+                     float* pts2, void* stream);
+
+/* _transform3 map stage + _interpolate from given homographies (spatial_transformer3.py:227-295). */
+int stabnet_maps_from_hs_fwd(const float* Hs, const float* U, int N, int H, int W, int C, int grid_h, int grid_w,
+                             float* out, float* black, float* x_map, float* y_map, void* stream);
+
+/* interpolate(im, x, y, out_size) -> output      spatial_transformer.py:200-281 (used train_bundle_nobm.py:117-118)
+ * im [N,H,W,C]; x,y [N,H,W] normalised coordinates; out [N,H,W,C]. */
+int stabnet_interp_fwd(const float* im, const float* x, const float* y, int N, int H, int W, int C, float* out,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STABNET_HIP_H */

@@ -1,0 +1,643 @@
+"""CPU oracle for the StabNet hot path (NumPy, float32 arithmetic op-for-op).
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package imports this file; only
+`tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` do, and
+only as the checker.
+
+PARITY UNPINNED: the reference (TensorFlow 1.3 + tf.contrib.slim + cv2) cannot be
+imported in the build container (modules absent, no network) and ships no tests,
+golden vectors or fixtures for this path.  This file is a
+restatement made by reading the reference sources as text; every function cites the
+reference file:line it follows.  Third-party arithmetic that is not under
+/root/reference (pinned only by README.md:8 `tensorflow-gpu==1.3.0`) is restated from
+its published algorithm and flagged `[external]`:
+  * tf.linspace (LinSpaceOp CPU kernel): `start + step * i`, step = (stop-start)/(n-1)
+  * tf.matrix_inverse -> Eigen 3.3 PartialPivLU::inverse (unblocked LU for n <= 16,
+    column-oriented triangular solves multiplying by the reciprocal diagonal)
+  * tf.contrib.slim.nets.resnet_v2.resnet_v2_50 / batch_norm / max_pool2d / fully_connected
+  * tf.round = round-half-to-even; float->int32 cast with x86 cvttss2si semantics
+
+All arithmetic is float32 with one rounding per TF op (TF 1.3 CPU wheels are built
+without FMA, and every elementwise TF op is its own kernel), so the HIP warp path can
+be compared bit-for-bit.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+F = np.float32
+INT_MIN = np.int32(-2147483648)
+
+
+# --------------------------------------------------------------------------- config
+@dataclass
+class Config:
+    """Constants of configs/v2_93.py:3-49 (only those the hot path reads)."""
+    height: int = 288
+    width: int = 512
+    batch_size: int = 10
+    grid_h: int = 4
+    grid_w: int = 4
+    before_ch: int = 6
+    tot_ch: int = 7
+    input_mask: bool = True
+    do_crop_rate: float = 0.8
+    max_matches: int = 3000
+    feature_mul: float = 1
+    theta_mul: float = 400 / 2500
+    regu_mul: float = 30 / 2500
+    img_mul: float = 50
+    temp_mul: float = 500
+    black_mul: float = 300000 / 2500
+    id_mul: float = 10 / 2500
+    distortion_mul: float = 1
+    consistency_mul: float = 20
+    grid_theta_mul: float = 0
+    weight_decay_fc: float = 0.0002      # hyper_parameters.py:38 via resnet.py:35-37
+    weight_decay_conv: float = 0.0001    # [external] slim resnet_arg_scope default
+    bn_eps: float = 1e-5                 # [external] slim resnet_arg_scope default
+    bn_decay: float = 0.997              # [external]
+    indices: tuple = (0, 1, 2, 4, 8, 16, 32)
+
+    @property
+    def in_ch(self):
+        return self.tot_ch + self.before_ch if self.input_mask else self.tot_ch
+
+
+def _f(x):
+    return np.asarray(x, dtype=F)
+
+
+# --------------------------------------------------------------------------- mesh
+def get_4_pts(theta, cfg: Config):
+    """s_net_bundle_nobm.py:29-71.  theta [N,(gh+1)(gw+1)2] -> pts1 [N,gh,gw,8], pts2 [N,gh+1,gw+1,2].
+
+    vertex(i,j) = (j*w-1, i*h-1) + theta[2*(i*(gw+1)+j) : +2]  (x first, :46-47,:55),
+    clipped to +-1/do_crop_rate (:37,:58).  pts1 per cell = [xTL,xTR,xBL,xBR,yTL,yTR,yBL,yBR]
+    (:65-66: concat of [N,2,1] columns along axis 2, then flatten).
+    """
+    theta = _f(theta)
+    N = theta.shape[0]
+    gh, gw = cfg.grid_h, cfg.grid_w
+    h = 2.0 / gh
+    w = 2.0 / gw
+    lim = F(1.0) / F(cfg.do_crop_rate)
+    pts2 = np.empty((N, gh + 1, gw + 1, 2), F)
+    tot = 0
+    for i in range(gh + 1):
+        for j in range(gw + 1):
+            base = np.array([j * w - 1, i * h - 1], dtype=F)
+            p = base[None, :] + theta[:, 2 * tot:2 * tot + 2]
+            p = np.minimum(np.maximum(p, -lim), lim)
+            pts2[:, i, j, :] = p
+            tot += 1
+    pts1 = np.empty((N, gh, gw, 8), F)
+    for i in range(gh):
+        for j in range(gw):
+            g = np.stack([pts2[:, i, j], pts2[:, i, j + 1], pts2[:, i + 1, j], pts2[:, i + 1, j + 1]], axis=2)
+            pts1[:, i, j, :] = g.reshape(N, 8)          # [N,2,4] -> x*4, y*4
+    return pts1, pts2
+
+
+# --------------------------------------------------------------------------- 8x8 inverse
+def inv8_partial_piv_lu(A):
+    """[external] tf.matrix_inverse == Eigen::PartialPivLU<Matrix>(A).inverse(), float32.
+
+    Restated for n = 8 (< Eigen's UnBlockedBound 16, so the unblocked right-looking LU runs):
+      for k: pivot = first argmax |a[k:,k]|; swap rows; a[k+1:,k] /= a[k,k];
+             a[k+1:,k+1:] -= a[k+1:,k] (x) a[k,k+1:]                       (mul then sub)
+      X = P*I; unit-lower solve then upper solve, both column oriented:
+             b = x[i,:] *= 1/u[i,i] (upper only);  x[rest,:] -= b * tri[rest,i]
+    A: [B,8,8] float32 -> inverse [B,8,8] float32.  Every op is a separate float32 rounding.
+    """
+    A = np.array(A, dtype=F, copy=True)
+    B, n, _ = A.shape
+    bi = np.arange(B)
+    perm = np.tile(np.arange(n), (B, 1))
+    for k in range(n):
+        piv = np.argmax(np.abs(A[:, k:, k]), axis=1) + k
+        rk = A[bi, k, :].copy()
+        rp = A[bi, piv, :].copy()
+        A[bi, k, :] = rp
+        A[bi, piv, :] = rk
+        pk = perm[bi, k].copy()
+        perm[bi, k] = perm[bi, piv]
+        perm[bi, piv] = pk
+        if k + 1 < n:
+            A[:, k + 1:, k] = A[:, k + 1:, k] / A[:, k, k][:, None]
+            prod = A[:, k + 1:, k][:, :, None] * A[:, k, k + 1:][:, None, :]
+            A[:, k + 1:, k + 1:] = A[:, k + 1:, k + 1:] - prod
+    X = np.zeros((B, n, n), F)
+    X[bi[:, None], np.arange(n)[None, :], perm] = F(1.0)      # X = P * I : row i has its 1 in column perm[i]
+    for i in range(n):                                         # unit-lower, ascending
+        b = X[:, i, :]
+        if i + 1 < n:
+            X[:, i + 1:, :] = X[:, i + 1:, :] - b[:, None, :] * A[:, i + 1:, i][:, :, None]
+    for i in range(n - 1, -1, -1):                             # upper, descending
+        a = F(1.0) / A[:, i, i]
+        X[:, i, :] = X[:, i, :] * a[:, None]
+        b = X[:, i, :]
+        if i > 0:
+            X[:, :i, :] = X[:, :i, :] - b[:, None, :] * A[:, :i, i][:, :, None]
+    return X
+
+
+def get_H(ori, tar):
+    """spatial_transformer3.py:144-175.  ori,tar [B,8] interleaved (x0,y0,...,x3,y3) -> [B,9].
+
+    A rows: 4 u-rows [x,y,1,0,0,0,-x*u,-y*u] then 4 v-rows [0,0,0,x,y,1,-x*v,-y*v] (:160-167);
+    b = [u0..u3,v0..v3] (:169); h = inv(A + eye(8)*1e-4) @ b (:145,:173); append 1.
+    """
+    ori = _f(ori)
+    tar = _f(tar)
+    B = ori.shape[0]
+    x, y = ori[:, 0::2], ori[:, 1::2]
+    u, v = tar[:, 0::2], tar[:, 1::2]
+    A = np.zeros((B, 8, 8), F)
+    for r in range(4):
+        A[:, r, 0] = x[:, r]
+        A[:, r, 1] = y[:, r]
+        A[:, r, 2] = 1
+        A[:, r, 6] = (-x[:, r]) * u[:, r]
+        A[:, r, 7] = (-y[:, r]) * u[:, r]
+        A[:, 4 + r, 3] = x[:, r]
+        A[:, 4 + r, 4] = y[:, r]
+        A[:, 4 + r, 5] = 1
+        A[:, 4 + r, 6] = (-x[:, r]) * v[:, r]
+        A[:, 4 + r, 7] = (-y[:, r]) * v[:, r]
+    b = np.concatenate([u, v], axis=1)
+    ridge = np.eye(8, dtype=F) * F(1e-4)
+    Ainv = inv8_partial_piv_lu(A + ridge[None])
+    h = np.zeros((B, 8), F)
+    for k in range(8):                                    # sequential k-sum of the batched matmul
+        h = h + Ainv[:, :, k] * b[:, k][:, None]
+    return np.concatenate([h, np.ones((B, 1), F)], axis=1)
+
+
+def get_Hs(pts2, cfg: Config):
+    """spatial_transformer3.py:179-198.  pts2 [N,gh+1,gw+1,2] -> Hs [N,gh,gw,9]."""
+    pts2 = _f(pts2)
+    N = pts2.shape[0]
+    gh, gw = cfg.grid_h, cfg.grid_w
+    h = 2.0 / gh
+    w = 2.0 / gw
+    Hs = np.empty((N, gh, gw, 9), F)
+    for i in range(gh):
+        for j in range(gw):
+            hh = i * h - 1
+            ww = j * w - 1
+            ori = np.tile(np.array([ww, hh, ww + w, hh, ww, hh + h, ww + w, hh + h], dtype=F)[None], (N, 1))
+            tar = np.concatenate([pts2[:, i, j], pts2[:, i, j + 1], pts2[:, i + 1, j], pts2[:, i + 1, j + 1]], axis=1)
+            Hs[:, i, j] = get_H(ori, tar)
+    return Hs
+
+
+def linspace_tf(start, stop, num):
+    """[external] TF 1.x LinSpaceOp: flat(i) = start + step * i, step = (stop - start)/(num - 1), in float32."""
+    start, stop = F(start), F(stop)
+    if num == 1:
+        return np.array([start], F)
+    step = (stop - start) / F(num - 1)
+    return start + step * np.arange(num, dtype=F)
+
+
+def cast_i32_x86(x):
+    """[external] tf.cast(float32 -> int32) on x86 (cvttss2si): out-of-range / NaN -> INT_MIN."""
+    x = _f(x)
+    ok = (x >= F(-2147483648.0)) & (x < F(2147483648.0))
+    return np.where(ok, np.where(ok, x, F(0)).astype(np.int32), INT_MIN).astype(np.int32)
+
+
+# --------------------------------------------------------------------------- sampler
+def _interpolate(im, x, y):
+    """spatial_transformer3.py:62-123 (identical copy spatial_transformer.py:209-270).
+
+    im [N,H,W,C]; x,y flat [N*H*W] normalised coords -> [N*H*W, C].
+    Corners are clipped BEFORE the weights are formed (:90-93,:114-121).
+    """
+    im = _f(im)
+    N, H, W, C = im.shape
+    x = _f(x)
+    y = _f(y)
+    xp = (x + F(1.0)) * F(W) / F(2.0)
+    yp = (y + F(1.0)) * F(H) / F(2.0)
+    x0 = cast_i32_x86(np.floor(xp))
+    x1 = x0 + np.int32(1)
+    y0 = cast_i32_x86(np.floor(yp))
+    y1 = y0 + np.int32(1)
+    x0 = np.clip(x0, 0, W - 1)
+    x1 = np.clip(x1, 0, W - 1)
+    y0 = np.clip(y0, 0, H - 1)
+    y1 = np.clip(y1, 0, H - 1)
+    base = np.repeat(np.arange(N, dtype=np.int64) * (H * W), x.size // N)
+    idx_a = base + y0.astype(np.int64) * W + x0
+    idx_b = base + y1.astype(np.int64) * W + x0
+    idx_c = base + y0.astype(np.int64) * W + x1
+    idx_d = base + y1.astype(np.int64) * W + x1
+    flat = im.reshape(-1, C)
+    Ia, Ib, Ic, Id = flat[idx_a], flat[idx_b], flat[idx_c], flat[idx_d]
+    x0f, x1f, y0f, y1f = x0.astype(F), x1.astype(F), y0.astype(F), y1.astype(F)
+    wa = ((x1f - xp) * (y1f - yp))[:, None]
+    wb = ((x1f - xp) * (yp - y0f))[:, None]
+    wc = ((xp - x0f) * (y1f - yp))[:, None]
+    wd = ((xp - x0f) * (yp - y0f))[:, None]
+    out = ((wa * Ia + wb * Ib) + wc * Ic) + wd * Id           # tf.add_n, left to right
+    return out, (x0, y0, x1, y1)
+
+
+def interpolate(im, x, y, out_size=None):
+    """spatial_transformer.py:200-281.  im [N,H,W,C]; x,y [N,H,W,1] -> [N,H,W,C]."""
+    im = _f(im)
+    N, H, W, C = im.shape
+    out, _ = _interpolate(im, _f(x).reshape(-1), _f(y).reshape(-1))
+    return out.reshape(N, H, W, C)
+
+
+# --------------------------------------------------------------------------- warp
+def cell_bounds(H, W, gh, gw):
+    """Pixel ownership of the cells, spatial_transformer3.py:227-243."""
+    ch = int(math.floor(H / gh))
+    cw = int(math.floor(W / gw))
+    rows = [(i * ch, (i + 1) * ch - 1 if i < gh - 1 else H - 1) for i in range(gh)]
+    cols = [(j * cw, (j + 1) * cw - 1 if j < gw - 1 else W - 1) for j in range(gw)]
+    return rows, cols
+
+
+def maps_from_Hs(Hs, H, W, cfg: Config):
+    """spatial_transformer3.py:200-214,227-286: per-cell H . (x,y,1), z += sign*1e-8, divide; black test."""
+    Hs = _f(Hs)
+    N = Hs.shape[0]
+    gh, gw = cfg.grid_h, cfg.grid_w
+    xs = linspace_tf(-1.0, 1.0, W)
+    ys = linspace_tf(-1.0, 1.0, H)
+    rows, cols = cell_bounds(H, W, gh, gw)
+    x_map = np.empty((N, H, W), F)
+    y_map = np.empty((N, H, W), F)
+    one = F(1.0)
+    for i, (sh, eh) in enumerate(rows):
+        for j, (sw, ew) in enumerate(cols):
+            h = Hs[:, i, j, :][:, :, None, None]                       # [N,9,1,1]
+            gx = xs[sw:ew + 1][None, None, :]
+            gy = ys[sh:eh + 1][None, :, None]
+            tx = (h[:, 0] * gx + h[:, 1] * gy) + h[:, 2] * one        # k-sequential matmul, :248
+            ty = (h[:, 3] * gx + h[:, 4] * gy) + h[:, 5] * one
+            tz = (h[:, 6] * gx + h[:, 7] * gy) + h[:, 8] * one
+            sign = np.where(tz >= 0, one, F(0.0)) * F(2.0) - one       # :257
+            tz = tz + sign * F(1e-8)                                   # :258
+            x_map[:, sh:eh + 1, sw:ew + 1] = tx / tz
+            y_map[:, sh:eh + 1, sw:ew + 1] = ty / tz
+    black = ((-one > x_map) | (x_map > one) | (-one > y_map) | (y_map > one)).astype(F)   # :284-286
+    return x_map, y_map, black
+
+
+def transformer(U, pts2, cfg: Config, return_all=False):
+    """spatial_transformer3.py:19,218-301,362-365.
+
+    U [N,H,W,C], pts2 [N,gh+1,gw+1,2] -> (output [N,H,W,C], black_pix [N,H,W], img [N,H,W,2]).
+    """
+    U = _f(U)
+    N, H, W, C = U.shape
+    Hs = get_Hs(pts2, cfg)
+    x_map, y_map, black = maps_from_Hs(Hs, H, W, cfg)
+    out, corners = _interpolate(U, x_map.reshape(-1), y_map.reshape(-1))
+    out = out.reshape(N, H, W, C)
+    img = np.stack([x_map, y_map], axis=3)
+    if return_all:
+        return out, black, img, Hs, corners
+    return out, black, img
+
+
+# --------------------------------------------------------------------------- losses
+def get_black_pos(pts1, cfg: Config):
+    """s_net_bundle_nobm.py:139-146: hinge of pts1 beyond +-1/do_crop_rate."""
+    pts1 = _f(pts1)
+    lim = F(1.0) / F(cfg.do_crop_rate)
+    z = F(0.0)
+    err = np.where(pts1 > lim, pts1 - lim, z) + np.where(-lim > pts1, -lim - pts1, z)
+    return err.reshape(pts1.shape[0], -1)
+
+
+def _calc_distortion(p0, p1, p2, clock, hw, cfg):
+    """s_net_bundle_nobm.py:148-164."""
+    h = 2.0 / cfg.grid_h
+    w = 2.0 / cfg.grid_w
+    k = h / w if hw == 0 else w / h
+    R = np.array([0, -k, k, 0] if not clock else [0, k, -k, 0], dtype=F).reshape(2, 2)
+    d = p1 - p0
+    rd = np.stack([R[0, 0] * d[:, 0] + R[0, 1] * d[:, 1], R[1, 0] * d[:, 0] + R[1, 1] * d[:, 1]], axis=1)
+    loss = np.abs(rd - (p2 - p1))
+    return loss * loss
+
+
+def get_distortion_loss(pts1, cfg: Config):
+    """s_net_bundle_nobm.py:166-181."""
+    pts = _f(pts1).reshape(-1, 2, 4)
+    p0, p1, p2, p3 = pts[:, :, 0], pts[:, :, 1], pts[:, :, 2], pts[:, :, 3]
+    loss = _calc_distortion(p0, p1, p3, 0, 0, cfg)
+    loss = loss + _calc_distortion(p1, p3, p2, 0, 1, cfg)
+    loss = loss + _calc_distortion(p3, p2, p0, 0, 0, cfg)
+    loss = loss + _calc_distortion(p2, p0, p1, 0, 1, cfg)
+    loss = loss + _calc_distortion(p1, p0, p2, 1, 0, cfg)
+    loss = loss + _calc_distortion(p0, p2, p3, 1, 1, cfg)
+    loss = loss + _calc_distortion(p2, p3, p1, 1, 0, cfg)
+    loss = loss + _calc_distortion(p3, p1, p0, 1, 1, cfg)
+    return F(np.mean(loss, dtype=np.float64)) / F(8)
+
+
+def get_consistency_loss(pts2, cfg: Config):
+    """s_net_bundle_nobm.py:183-210."""
+    p = _f(pts2)
+    gh, gw = cfg.grid_h, cfg.grid_w
+    errs = []
+    two = F(2.0)
+    for i in range(gh + 1):
+        for j in range(gw + 1):
+            if i > 1:
+                errs.append(np.abs(two * p[:, i - 1, j] - p[:, i, j] - p[:, i - 2, j]))
+            if j > 1:
+                errs.append(np.abs(two * p[:, i, j - 1] - p[:, i, j] - p[:, i, j - 2]))
+            if i < gh - 1:
+                errs.append(np.abs(two * p[:, i + 1, j] - p[:, i, j] - p[:, i + 2, j]))
+            if j < gw - 1:
+                errs.append(np.abs(two * p[:, i, j + 1] - p[:, i, j] - p[:, i, j + 2]))
+    if not errs:
+        return F(0.0)
+    e = np.stack(errs, axis=2)
+    return F(np.mean(e * e, dtype=np.float64))
+
+
+def warp_pts(pts, flow, cfg: Config):
+    """s_net_bundle_nobm.py:215-230.  pts [N,M,2] normalised, flow(maps) [N,H,W,2] -> [N,M,2]."""
+    pts = _f(pts)
+    flow = _f(flow)
+    N, H, W, _ = flow.shape
+    x = np.clip((pts[:, :, 0] + F(1)) / F(2) * F(W), F(0), F(W - 1))
+    y = np.clip((pts[:, :, 1] + F(1)) / F(2) * F(H), F(0), F(H - 1))
+    xi = np.rint(x).astype(np.int32)            # tf.round: half to even
+    yi = np.rint(y).astype(np.int32)
+    out = np.empty((N, pts.shape[1], 2), F)
+    for n in range(N):
+        out[n] = flow[n].reshape(-1, 2)[xi[n] + yi[n] * W]
+    return out, (xi, yi)
+
+
+def feature_loss(matches, mask, flow, cfg: Config):
+    """s_net_bundle_nobm.py:335-343."""
+    matches = _f(matches)
+    mask = _f(mask)
+    stable, unstable = matches[:, :, :2], matches[:, :, 2:]
+    warped, _ = warp_pts(stable, flow, cfg)
+    before = np.sum(np.abs(warped - unstable), axis=2, dtype=F)
+    after = np.sum(before * mask, axis=1, dtype=np.float64) / np.maximum(np.sum(mask, axis=1, dtype=np.float64), 1.0)
+    return F(np.mean(after)), warped
+
+
+def img_loss(h_trans, y, black_pix, cfg: Config):
+    """s_net_bundle_nobm.py:347-352 (divides by the STATIC batch_size)."""
+    h_trans = _f(h_trans)
+    N = h_trans.shape[0]
+    keep = F(1) - _f(black_pix).reshape(N, h_trans.shape[1], h_trans.shape[2], 1)
+    err = (h_trans - _f(y)) * keep
+    num = np.sum(err * err, axis=(1, 2, 3), dtype=np.float64)
+    den = np.sum(keep, axis=(1, 2, 3), dtype=np.float64) + 1e-8
+    return F(np.sum(num / den) / cfg.batch_size)
+
+
+def temporal_loss(out1, black1, out2, black2, flow, cfg: Config, use_temp_loss=1.0):
+    """train_bundle_nobm.py:110-125."""
+    out1, out2 = _f(out1), _f(out2)
+    N, H, W, _ = out1.shape
+    fx, fy = _f(flow)[..., 0:1], _f(flow)[..., 1:2]
+    o2 = interpolate(out2, fx, fy)
+    nb2 = interpolate((F(1) - _f(black2)).reshape(N, H, W, 1), fx, fy)
+    err = out1 - o2
+    noblack = (F(1) - _f(black1)).reshape(N, H, W, 1) * nb2
+    err = err * noblack
+    num = np.sum(err * err, axis=(1, 2, 3), dtype=np.float64)
+    den = np.sum(noblack, axis=(1, 2, 3), dtype=np.float64) + 1e-8
+    return F(np.sum(num / den) / cfg.batch_size * use_temp_loss)
+
+
+# --------------------------------------------------------------------------- backbone  [external] slim
+def _same_pads(n, k, s):
+    out = -(-n // s)
+    tot = max((out - 1) * s + k - n, 0)
+    return tot // 2, tot - tot // 2
+
+
+def conv2d(x, w, stride=1, pads=((0, 0), (0, 0)), bias=None):
+    """NHWC x, HWIO w, explicit zero pads, VALID after padding; im2col + one sgemm."""
+    x = _f(x)
+    w = _f(w)
+    kh, kw, ci, co = w.shape
+    if pads != ((0, 0), (0, 0)):
+        x = np.pad(x, ((0, 0), pads[0], pads[1], (0, 0)))
+    N, H, W, _ = x.shape
+    Ho = (H - kh) // stride + 1
+    Wo = (W - kw) // stride + 1
+    if kh == 1 and kw == 1:
+        cols = x[:, ::stride, ::stride, :][:, :Ho, :Wo, :].reshape(-1, ci)
+    else:
+        s0, s1, s2, s3 = x.strides
+        v = np.lib.stride_tricks.as_strided(
+            x, (N, Ho, Wo, kh, kw, ci), (s0, s1 * stride, s2 * stride, s1, s2, s3), writeable=False)
+        cols = np.ascontiguousarray(v).reshape(N * Ho * Wo, kh * kw * ci)
+    y = cols @ w.reshape(kh * kw * ci, co)
+    if bias is not None:
+        y = y + _f(bias)[None, :]
+    return y.reshape(N, Ho, Wo, co)
+
+
+def conv2d_same(x, w, stride, bias=None):
+    """[external] slim resnet_utils.conv2d_same: stride 1 -> SAME; else explicit symmetric-ish pad + VALID."""
+    k = w.shape[0]
+    if stride == 1:
+        ph = _same_pads(x.shape[1], k, 1)
+        pw = _same_pads(x.shape[2], k, 1)
+        return conv2d(x, w, 1, (ph, pw), bias)
+    tot = k - 1
+    beg = tot // 2
+    end = tot - beg
+    return conv2d(x, w, stride, ((beg, end), (beg, end)), bias)
+
+
+def max_pool_3x3_s2_same(x):
+    """[external] slim max_pool2d(3, stride 2, padding='SAME'): TF-SAME pads (before=tot//2, after=rest) with -inf."""
+    x = _f(x)
+    ph = _same_pads(x.shape[1], 3, 2)
+    pw = _same_pads(x.shape[2], 3, 2)
+    xp = np.pad(x, ((0, 0), ph, pw, (0, 0)), constant_values=-np.inf)
+    N, H, W, C = xp.shape
+    Ho = (H - 3) // 2 + 1
+    Wo = (W - 3) // 2 + 1
+    out = np.full((N, Ho, Wo, C), -np.inf, F)
+    for dy in range(3):
+        for dx in range(3):
+            out = np.maximum(out, xp[:, dy:dy + 2 * Ho:2, dx:dx + 2 * Wo:2, :][:, :Ho, :Wo, :])
+    return out
+
+
+def batch_norm(x, p, prefix, cfg: Config, training=False, stats_out=None):
+    """[external] slim batch_norm (non-fused, TF 1.3): tf.nn.batch_normalization:
+    inv = rsqrt(var+eps)*gamma;  y = x*inv + (beta - mean*inv).
+    training=True uses tf.nn.moments batch statistics (biased variance)."""
+    x = _f(x)
+    gamma, beta = _f(p[prefix + '/gamma']), _f(p[prefix + '/beta'])
+    if training:
+        x64 = x.astype(np.float64)
+        mean = x64.mean(axis=(0, 1, 2))
+        var = ((x64 - mean) ** 2).mean(axis=(0, 1, 2))
+        mean, var = mean.astype(F), var.astype(F)
+        if stats_out is not None:
+            stats_out[prefix] = (mean, var)
+    else:
+        mean, var = _f(p[prefix + '/moving_mean']), _f(p[prefix + '/moving_variance'])
+    inv = (F(1.0) / np.sqrt(var + F(cfg.bn_eps))) * gamma
+    return x * inv + (beta - mean * inv)
+
+
+def relu(x):
+    return np.maximum(x, F(0))
+
+
+RESNET_V2_50_BLOCKS = (      # (depth, bottleneck depth, units, stride on the LAST unit)  [external] slim resnet_v2_50
+    ('block1', 256, 64, 3, 2),
+    ('block2', 512, 128, 4, 2),
+    ('block3', 1024, 256, 6, 2),
+    ('block4', 2048, 512, 3, 1),
+)
+
+
+def resnet_v2_50(x, p, cfg: Config, training=False, stats_out=None, taps=None):
+    """[external] slim resnet_v2_50(x, global_pool=False, output_stride=32) under resnet_arg_scope(),
+    as called at s_net_bundle_nobm.py:252-253.  p: name -> array, TF layouts."""
+    R = 'resnet_v2_50/'
+    net = conv2d_same(x, p[R + 'conv1/weights'], 2, p[R + 'conv1/biases'])          # bias, no BN/ReLU
+    if taps is not None:
+        taps['conv1'] = net
+    net = max_pool_3x3_s2_same(net)
+    if taps is not None:
+        taps['pool1'] = net
+    for (bname, depth, dbn, units, bstride) in RESNET_V2_50_BLOCKS:
+        for u in range(1, units + 1):
+            stride = bstride if u == units else 1
+            S = R + '%s/unit_%d/bottleneck_v2/' % (bname, u)
+            depth_in = net.shape[3]
+            preact = relu(batch_norm(net, p, S + 'preact', cfg, training, stats_out))
+            if depth == depth_in:
+                shortcut = net if stride == 1 else net[:, ::stride, ::stride, :]      # max_pool 1x1 stride s
+            else:
+                shortcut = conv2d(preact, p[S + 'shortcut/weights'], stride, bias=p[S + 'shortcut/biases'])
+            r = conv2d(preact, p[S + 'conv1/weights'], 1)
+            r = relu(batch_norm(r, p, S + 'conv1/BatchNorm', cfg, training, stats_out))
+            r = conv2d_same(r, p[S + 'conv2/weights'], stride)
+            r = relu(batch_norm(r, p, S + 'conv2/BatchNorm', cfg, training, stats_out))
+            r = conv2d(r, p[S + 'conv3/weights'], 1, bias=p[S + 'conv3/biases'])
+            net = shortcut + r
+            if taps is not None:
+                taps['%s/unit_%d' % (bname, u)] = net
+    net = relu(batch_norm(net, p, R + 'postnorm', cfg, training, stats_out))
+    return net
+
+
+def get_resnet(x_tensor, p, cfg: Config, training=False, stats_out=None, taps=None):
+    """s_net_bundle_nobm.py:250-264: backbone -> reduce_mean(1,2) -> FC 2048/1024/512 (ReLU) -> output_layer.
+    Returns (theta [N,(gh+1)(gw+1)2], id_loss, id2_loss)."""
+    feat = resnet_v2_50(x_tensor, p, cfg, training, stats_out, taps)
+    g = feat.mean(axis=(1, 2), dtype=np.float64).astype(F)
+    if taps is not None:
+        taps['global_pool'] = g
+    for k in (1, 2, 3):
+        g = relu(g @ _f(p['fc/fc/fc_%d/weights' % k]) + _f(p['fc/fc/fc_%d/biases' % k]))
+    theta = g @ _f(p['fc/fc_weights']) + _f(p['fc/fc_bias'])                       # resnet.py:44-56
+    id2 = F(np.mean(np.abs(theta), dtype=np.float64)) * F(cfg.id_mul)              # :263
+    return theta, id2, id2
+
+
+def regu_loss(p, cfg: Config):
+    """s_net_bundle_nobm.py:324-325: add_n(REGULARIZATION_LOSSES): slim conv weights 1e-4*l2_loss(w) ([external]
+    resnet_arg_scope; biases/BN/fully_connected carry none), fc_weights & fc_bias 2e-4*l2_loss (resnet.py:35-37)."""
+    tot = 0.0
+    for name, v in p.items():
+        v64 = np.asarray(v, np.float64)
+        if name.startswith('resnet_v2_50/') and name.endswith('/weights'):
+            tot += cfg.weight_decay_conv * 0.5 * np.sum(v64 * v64)
+        elif name in ('fc/fc_weights', 'fc/fc_bias'):
+            tot += cfg.weight_decay_fc * 0.5 * np.sum(v64 * v64)
+    return F(tot)
+
+
+# --------------------------------------------------------------------------- tower
+def inference_stable_net(x_tensor, p, cfg: Config, y=None, matches=None, mask=None,
+                         use_black_loss=1.0, use_theta_only=0.0, training=False):
+    """s_net_bundle_nobm.py:266-385, one tower.  With y/matches/mask=None only the inference outputs are made
+    (the contract of deploy_bundle.py:48-56,286)."""
+    x_tensor = _f(x_tensor)
+    cur = cfg.before_ch + cfg.before_ch if cfg.input_mask else cfg.before_ch
+    x = x_tensor[..., cur:cur + 1]                                                   # :281
+    theta, id_loss, id2_loss = get_resnet(x_tensor, p, cfg, training)
+    pts1, pts2 = get_4_pts(theta, cfg)
+    out, black, flow, Hs, _ = transformer(x, pts2, cfg, return_all=True)
+    ret = {'theta': theta, 'pts1': pts1, 'pts2': pts2, 'output': out, 'black_pix': black,
+           'x_map': flow[..., 0:1], 'y_map': flow[..., 1:2], 'Hs': Hs,
+           'theta_loss': id_loss * F(cfg.theta_mul), 'grid_theta_loss': id2_loss * F(cfg.grid_theta_mul)}
+    if y is None:
+        return ret
+    bp = get_black_pos(pts1, cfg)
+    bp = bp * bp * F(use_black_loss)
+    black_pos_loss = F(np.mean(bp, dtype=np.float64))
+    regu = regu_loss(p, cfg)
+    dist = get_distortion_loss(pts1, cfg)
+    cons = get_consistency_loss(pts2, cfg)
+    feat, warped = feature_loss(matches, mask, flow, cfg)
+    il = img_loss(out, y, black, cfg)
+    total = (id_loss * F(cfg.theta_mul) + id2_loss * F(cfg.grid_theta_mul) + (F(1) - F(use_theta_only)) * (
+        il * F(cfg.img_mul) + regu * F(cfg.regu_mul) + black_pos_loss * F(cfg.black_mul)
+        + dist * F(cfg.distortion_mul) + cons * F(cfg.consistency_mul) + feat * F(cfg.feature_mul)))
+    ret.update({'error': np.abs(out - _f(y)), 'black_pos': bp, 'black_loss': black_pos_loss * F(cfg.black_mul),
+                'distortion_loss': dist * F(cfg.distortion_mul), 'consistency_loss': cons * F(cfg.consistency_mul),
+                'feature_loss': feat * F(cfg.feature_mul), 'img_loss': il * F(cfg.img_mul),
+                'regu_loss': regu * F(cfg.regu_mul), 'total_loss': F(total), 'stable_warpped': warped})
+    return ret
+
+
+# --------------------------------------------------------------------------- deploy loop
+class DeployRing:
+    """deploy_bundle.py:204-232,259-274,291-295,319-332: history of stabilised frames + black masks,
+    `before_ch = max(indices[1:])` deep (:34,:41), sampled at the dilated lags."""
+
+    def __init__(self, first_frame, cfg: Config):
+        self.cfg = cfg
+        self.lags = [i for i in cfg.indices[1:] if i > 0]
+        depth = max(self.lags)
+        f0 = _f(first_frame).reshape(1, cfg.height, cfg.width, 1)
+        self.frames = [f0.copy() for _ in range(depth)]                               # :216-217
+        self.masks = [np.zeros((1, cfg.height, cfg.width, 1), F) for _ in range(depth)]   # :218
+
+    def stack(self, cur):
+        parts = [self.masks[-i] for i in self.lags] + [self.frames[-i] for i in self.lags]
+        parts.append(_f(cur).reshape(1, self.cfg.height, self.cfg.width, 1))
+        return np.concatenate(parts, axis=3)                                          # :259-274
+
+    def push(self, frame, black):
+        self.frames.append(_f(frame).reshape(1, self.cfg.height, self.cfg.width, 1))  # :322
+        self.masks.append(_f(black).reshape(1, self.cfg.height, self.cfg.width, 1))   # :323
+        self.frames.pop(0)
+        self.masks.pop(0)
+
+
+def deploy_step(ring: DeployRing, cur, p, cfg: Config, refine=1):
+    """One iteration of the hot loop, deploy_bundle.py:259-296,319-332 (network + feedback only)."""
+    in_x = ring.stack(cur)
+    tmp = in_x.copy()
+    for _ in range(refine):
+        r = inference_stable_net(tmp, p, cfg)
+        img = r['output'][0, :, :, 0]
+        black = r['black_pix'][0]
+        frame = img + black * F(-1)                                                   # :293
+        tmp[..., -1] = frame[None]
+    ring.push(frame, black)
+    return r, frame
