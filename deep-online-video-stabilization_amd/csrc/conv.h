@@ -1,0 +1,27 @@
+// Internal launcher interface of the implicit-GEMM convolution kernels (conv.hip).
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+    // tensors
+    const float* x;          // input  NHWC [N,H,W,Cin]
+    const float* w;          // weights OHWI [Cout][KH][KW][Cin]   (row n = one output channel, K contiguous)
+    float* y;                // output NHWC [N,Ho,Wo,Cout]
+    const float* bias;       // [Cout] or null
+    const float* in_scale;   // [Cin] or null: A-operand prologue  a = relu(a*scale + shift)  (folded BN + ReLU)
+    const float* in_shift;   // [Cin]
+    const float* residual;   // NHWC [N,res_H,res_W,Cout] or null; read at (oy*res_stride, ox*res_stride)
+    float* partial;          // split-K workspace [splitk][M][Cout] (only when splitk > 1)
+    // geometry
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+    int up;                  // input dilation ("fractional stride") used by dgrad of strided convs; 1 otherwise
+    int res_H, res_W, res_stride;
+    int relu_out;
+    int M, K;                // M = N*Ho*Wo, K = KH*KW*Cin
+    int splitk, steps_per_split;
+};
+
+// Chooses tile shape / split-K and returns the workspace bytes the launch needs (0 if none).
+size_t conv_plan(ConvArgs& a);
+// Enqueues the convolution (and the split-K reduction when a.splitk > 1).
+int conv_launch(const ConvArgs& a, hipStream_t st);

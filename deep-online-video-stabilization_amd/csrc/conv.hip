@@ -1,0 +1,378 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores, exact float32 (v_mfma_f32_32x32x2_f32).
+//
+//   y[m][n] = sum_k A(m,k) * Wt[n][k]      m = (img, oy, ox)   k = (kh, kw, c)   n = output channel
+//   A(m,k)  = act( x[img, oy*stride-pad+kh, ox*stride-pad+kw, c] )   act = optional folded BN + ReLU (prologue)
+//
+// Replaces the slim conv2d / conv2d_same (+ batch_norm + relu) clusters of resnet_v2_50 called at
+// s_net_bundle_nobm.py:252-253 (SURVEY.md section 2.1 rows K1,K3,K4,K5).
+//
+// Tiling: 256 threads = 4 waves (64 lanes).  Block tile BM x BN, K-step BK; both operands are staged in LDS with
+// the reduction index contiguous ([row][BK+4] floats, rows 16-B aligned, pitch 36/20 dwords = conflict-free
+// ds_read_b128 for the 16-lane service groups).  Lane (i = lane&31, h = lane>>5) of a wave reads FOUR consecutive
+// k (one ds_read_b128) of row i at k-offset 8*kk + 4*h and feeds them to four successive MFMAs: the MFMA's two
+// k-slots are thus k = 8kk+e and 8kk+4+e for A and B alike -- a permutation of the reduction order only.
+// Global->LDS staging goes through registers (the BN+ReLU prologue and the im2col zero padding need the VALU),
+// issued one K-step ahead of the MFMAs (double-buffered LDS, one barrier per K-step).
+#include "conv.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
+    constexpr int PITCH = BK + 4;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int F4_PER_ROW = BK / 4;
+    constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+    constexpr int A_PASSES = BM / ROWS_PER_PASS;
+    constexpr int B_PASSES = BN / ROWS_PER_PASS;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    static_assert(A_PASSES >= 1 && B_PASSES >= 1, "tile too small for the loader");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As0 = smem;
+    float* const Bs0 = smem + BM * PITCH;
+    constexpr int STAGE = (BM + BN) * PITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    const int cin_steps = p.Cin / BK;
+    const int total_steps = p.KH * p.KW * cin_steps;
+    const int ks_begin = blockIdx.z * p.steps_per_split;
+    const int ks_end = min(total_steps, ks_begin + p.steps_per_split);
+
+    // ---- loader mapping: thread -> (row within pass, float4 within the BK slice)
+    const int lrow = tid / F4_PER_ROW, lc4 = tid % F4_PER_ROW;
+    int a_base[A_PASSES], a_iy0[A_PASSES], a_ix0[A_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < A_PASSES; ++ps) {
+        const int m = m0 + lrow + ps * ROWS_PER_PASS;
+        if (m < p.M) {
+            const int img = m / (p.Ho * p.Wo);
+            const int r = m - img * (p.Ho * p.Wo);
+            const int oy = r / p.Wo, ox = r - oy * p.Wo;
+            a_base[ps] = img * p.H;
+            a_iy0[ps] = oy * p.stride - p.pad;
+            a_ix0[ps] = ox * p.stride - p.pad;
+        } else {
+            a_base[ps] = -1;
+            a_iy0[ps] = 0;
+            a_ix0[ps] = 0;
+        }
+    }
+    const float* wrow[B_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < B_PASSES; ++ps) {
+        const int n = n0 + lrow + ps * ROWS_PER_PASS;
+        wrow[ps] = (n < p.Cout) ? p.w + (size_t)n * p.K + lc4 * 4 : nullptr;
+    }
+
+    float4 ra[A_PASSES], rb[B_PASSES];
+    auto load_tiles = [&](int ks) {
+        const int tap = ks / cin_steps;
+        const int c0 = (ks - tap * cin_steps) * BK;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.in_scale != nullptr) {
+            sc = *reinterpret_cast<const float4*>(p.in_scale + c0 + lc4 * 4);
+            sh = *reinterpret_cast<const float4*>(p.in_shift + c0 + lc4 * 4);
+        }
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps) {
+            int iy = a_iy0[ps] + kh, ix = a_ix0[ps] + kw;
+            bool ok = a_base[ps] >= 0 && iy >= 0 && ix >= 0;
+            if (p.up > 1) {
+                ok = ok && (iy % p.up == 0) && (ix % p.up == 0);
+                iy /= p.up;
+                ix /= p.up;
+            }
+            ok = ok && iy < p.H && ix < p.W;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                v = *reinterpret_cast<const float4*>(p.x + ((size_t)(a_base[ps] + iy) * p.W + ix) * p.Cin + c0 + lc4 * 4);
+                if (p.in_scale != nullptr) {
+                    v.x = fmaxf(v.x * sc.x + sh.x, 0.f);
+                    v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
+                    v.z = fmaxf(v.z * sc.z + sh.z, 0.f);
+                    v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
+                }
+            }
+            ra[ps] = v;
+        }
+#pragma unroll
+        for (int ps = 0; ps < B_PASSES; ++ps) {
+            rb[ps] = (wrow[ps] != nullptr) ? *reinterpret_cast<const float4*>(wrow[ps] + (size_t)tap * p.Cin + c0)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* As = As0 + buf * STAGE;
+        float* Bs = Bs0 + buf * STAGE;
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps)
+            *reinterpret_cast<float4*>(As + (lrow + ps * ROWS_PER_PASS) * PITCH + lc4 * 4) = ra[ps];
+#pragma unroll
+        for (int ps = 0; ps < B_PASSES; ++ps)
+            *reinterpret_cast<float4*>(Bs + (lrow + ps * ROWS_PER_PASS) * PITCH + lc4 * 4) = rb[ps];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (ks_begin < ks_end) {
+        load_tiles(ks_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    const int frag_off = (lane & 31) * PITCH + (lane >> 5) * 4;
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+        const int buf = (ks - ks_begin) & 1;
+        if (ks + 1 < ks_end) load_tiles(ks + 1);          // global loads in flight under the MFMAs
+        const float* Ab = As0 + buf * STAGE + (wm * WM) * PITCH + frag_off;
+        const float* Bb = Bs0 + buf * STAGE + (wn * WN) * PITCH + frag_off;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * PITCH + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * PITCH + kk * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (ks + 1 < ks_end) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool split = p.splitk > 1;
+    float* const outp = split ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : p.y;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+        if (n >= p.Cout) continue;
+        const float bv = (!split && p.bias != nullptr) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                float v = acc[i][j][r];
+                if (!split) {
+                    v += bv;
+                    if (p.residual != nullptr) {
+                        size_t ri;
+                        if (p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo) {
+                            ri = (size_t)m * p.Cout + n;
+                        } else {
+                            const int img = m / (p.Ho * p.Wo);
+                            const int rr = m - img * (p.Ho * p.Wo);
+                            const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
+                            ri = (((size_t)img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.Cout + n;
+                        }
+                        v += p.residual[ri];
+                    }
+                    if (p.relu_out) v = fmaxf(v, 0.f);
+                }
+                outp[(size_t)m * p.Cout + n] = v;
+            }
+        }
+    }
+}
+
+// Sums the split-K partial slabs in a fixed order and applies the epilogue.  One thread per 4 channels.
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs p) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = p.Cout / 4;
+    if (q >= (size_t)p.M * c4n) return;
+    const int m = (int)(q / c4n);
+    const int n = (int)(q - (size_t)m * c4n) * 4;
+    const size_t slab = (size_t)p.M * p.Cout;
+    const float* src = p.partial + (size_t)m * p.Cout + n;
+    float4 s = *reinterpret_cast<const float4*>(src);
+    for (int z = 1; z < p.splitk; ++z) {
+        const float4 t = *reinterpret_cast<const float4*>(src + z * slab);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    if (p.bias != nullptr) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    if (p.residual != nullptr) {
+        size_t ri;
+        if (p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo) {
+            ri = (size_t)m * p.Cout + n;
+        } else {
+            const int img = m / (p.Ho * p.Wo);
+            const int rr = m - img * (p.Ho * p.Wo);
+            const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
+            ri = (((size_t)img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.Cout + n;
+        }
+        const float4 t = *reinterpret_cast<const float4*>(p.residual + ri);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    if (p.relu_out) {
+        s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n) = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+enum TileId { T128x128 = 0, T128x64 = 1, T64x64 = 2 };
+
+static void tile_dims(int t, int& bm, int& bn) {
+    bm = (t == T64x64) ? 64 : 128;
+    bn = (t == T128x128) ? 128 : 64;
+}
+
+static int pick_tile(const ConvArgs& a, int& splitk) {
+    const int bk = (a.Cin % 32 == 0) ? 32 : 16;
+    const int total_steps = a.KH * a.KW * (a.Cin / bk);
+    const int target = 512;                       // >= 2 blocks per CU over the 256 CUs
+    int best = T64x64;
+    for (int t = 0; t < 3; ++t) {
+        int bm, bn;
+        tile_dims(t, bm, bn);
+        if (bn > a.Cout && t != T64x64) continue;
+        const long blocks = (long)cdiv(a.M, bm) * cdiv(a.Cout, bn);
+        if (blocks >= target) { best = t; splitk = 1; return best; }
+    }
+    int bm, bn;
+    tile_dims(best, bm, bn);
+    const long blocks = (long)cdiv(a.M, bm) * cdiv(a.Cout, bn);
+    int s = (int)((target + blocks - 1) / blocks);
+    s = min(s, max(1, total_steps / 8));          // keep >= 8 K-steps per slice
+    s = min(s, 32);
+    if (a.Cout % 4 != 0) s = 1;
+    splitk = max(1, s);
+    return best;
+}
+
+size_t conv_plan(ConvArgs& a) {
+    a.M = a.N * a.Ho * a.Wo;
+    a.K = a.KH * a.KW * a.Cin;
+    int splitk = 1;
+    (void)pick_tile(a, splitk);
+    const int bk = (a.Cin % 32 == 0) ? 32 : 16;
+    const int total_steps = a.KH * a.KW * (a.Cin / bk);
+    a.steps_per_split = cdiv(total_steps, splitk);
+    a.splitk = cdiv(total_steps, a.steps_per_split);
+    return a.splitk > 1 ? (size_t)a.splitk * a.M * a.Cout * sizeof(float) : 0;
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+static int launch_one(const ConvArgs& a, hipStream_t st) {
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
+    static bool configured = false;
+    auto kern = conv_igemm_f32_kernel<BM, BN, BK, WM, WN>;
+    if (!configured) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                stabnet_set_error("conv: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+                return STABNET_ERR_LAUNCH;
+            }
+        }
+        configured = true;
+    }
+    dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN), a.splitk);
+    kern<<<grid, 256, lds, st>>>(a);
+    SN_LAUNCH_CHECK("conv_igemm_f32_kernel");
+    return STABNET_OK;
+}
+
+int conv_launch(const ConvArgs& a, hipStream_t st) {
+    SN_REQUIRE(a.Cin % 16 == 0, "conv: Cin=%d must be a multiple of 16 (pad the channels)", a.Cin);
+    SN_REQUIRE(a.splitk >= 1 && a.steps_per_split >= 1, "conv: conv_plan() not called");
+    SN_REQUIRE(a.splitk == 1 || a.partial != nullptr, "conv: split-K needs a workspace");
+    int splitk_unused = 1;
+    const int t = pick_tile(a, splitk_unused);
+    const bool bk32 = (a.Cin % 32 == 0);
+    int rc;
+    if (bk32) {
+        if (t == T128x128) rc = launch_one<128, 128, 32, 64, 64>(a, st);
+        else if (t == T128x64) rc = launch_one<128, 64, 32, 64, 32>(a, st);
+        else rc = launch_one<64, 64, 32, 32, 32>(a, st);
+    } else {
+        if (t == T128x128) rc = launch_one<128, 128, 16, 64, 64>(a, st);
+        else if (t == T128x64) rc = launch_one<128, 64, 16, 64, 32>(a, st);
+        else rc = launch_one<64, 64, 16, 32, 32>(a, st);
+    }
+    if (rc) return rc;
+    if (a.splitk > 1) {
+        const size_t q = (size_t)a.M * (a.Cout / 4);
+        conv_splitk_reduce_kernel<<<cdiv((long)q, 256), 256, 0, st>>>(a);
+        SN_LAUNCH_CHECK("conv_splitk_reduce_kernel");
+    }
+    return STABNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static int fill_args(ConvArgs& a, const float* x, const float* w, const float* bias, const float* in_scale,
+                     const float* in_shift, const float* residual, int res_H, int res_W, int res_stride, float* y,
+                     int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu_out) {
+    SN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+               "conv2d: bad geometry");
+    SN_REQUIRE(Cin % 16 == 0, "conv2d: Cin=%d must be a multiple of 16", Cin);
+    SN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d: in_scale and in_shift go together");
+    a = ConvArgs{};
+    a.x = x; a.w = w; a.y = y; a.bias = bias; a.in_scale = in_scale; a.in_shift = in_shift; a.residual = residual;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.up = 1;
+    a.Ho = (H + 2 * pad - KH) / stride + 1;
+    a.Wo = (W + 2 * pad - KW) / stride + 1;
+    SN_REQUIRE(a.Ho > 0 && a.Wo > 0, "conv2d: empty output");
+    a.res_H = residual ? res_H : a.Ho;
+    a.res_W = residual ? res_W : a.Wo;
+    a.res_stride = residual ? res_stride : 1;
+    a.relu_out = relu_out;
+    SN_REQUIRE((long)N * a.Ho * a.Wo < (1L << 31) && (long)N * H * W * Cin < (1L << 40), "conv2d: too large");
+    return STABNET_OK;
+}
+
+extern "C" {
+
+size_t stabnet_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    ConvArgs a;
+    if (fill_args(a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, nullptr, N, H, W, Cin, Cout, KH, KW,
+                  stride, pad, 0))
+        return 0;
+    return conv_plan(a);
+}
+
+int stabnet_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, const float* in_scale,
+                       const float* in_shift, const float* residual, int res_H, int res_W, int res_stride, float* y,
+                       int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu_out,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    SN_REQUIRE(x && w_ohwi && y, "conv2d_fwd: null pointer");
+    ConvArgs a;
+    int rc = fill_args(a, x, w_ohwi, bias, in_scale, in_shift, residual, res_H, res_W, res_stride, y, N, H, W, Cin, Cout,
+                       KH, KW, stride, pad, relu_out);
+    if (rc) return rc;
+    const size_t need = conv_plan(a);
+    if (need > workspace_bytes || (need > 0 && workspace == nullptr)) {
+        stabnet_set_error("conv2d_fwd: workspace %zu B < %zu B needed", workspace_bytes, need);
+        return STABNET_ERR_WORKSPACE;
+    }
+    a.partial = static_cast<float*>(workspace);
+    return conv_launch(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

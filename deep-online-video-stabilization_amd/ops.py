@@ -1,0 +1,42 @@
+"""Thin host wrappers of the regressor building blocks of the C ABI (used by tests and by regressor.py)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._tensor import dev_f32, empty, ptr, stream_ptr
+
+
+def pack_conv_weight(w_hwio, cin_pad: int = 16) -> np.ndarray:
+    """TF HWIO [kh,kw,Cin,Cout] -> the library's OHWI [Cout,kh,kw,Cin'] with Cin' = Cin rounded up to `cin_pad`."""
+    w = np.asarray(w_hwio, np.float32)
+    kh, kw, ci, co = w.shape
+    cp = -(-ci // cin_pad) * cin_pad
+    out = np.zeros((co, kh, kw, cp), np.float32)
+    out[..., :ci] = np.transpose(w, (3, 0, 1, 2))
+    return out
+
+
+def unpack_conv_weight(w_ohwi, cin: int) -> np.ndarray:
+    return np.ascontiguousarray(np.transpose(np.asarray(w_ohwi, np.float32)[..., :cin], (1, 2, 3, 0)))
+
+
+def conv2d(x, w_ohwi, bias=None, in_scale=None, in_shift=None, residual=None, res_stride=1, stride=1, pad=0,
+           relu_out=False):
+    x = dev_f32(x, "x")
+    w = dev_f32(w_ohwi, "w")
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, Cw = w.shape
+    assert Cw == Cin, "weight Cin %d != input Cin %d" % (Cw, Cin)
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    y = empty((N, Ho, Wo, Cout), x)
+    L = _lib.lib()
+    ws_bytes = L.stabnet_conv2d_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=x.device)
+    rH, rW = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)
+    _lib.call("stabnet_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(residual), rH, rW,
+              res_stride, ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, int(relu_out), ptr(ws), ws_bytes,
+              stream_ptr())
+    return y

@@ -57,6 +57,21 @@ int stabnet_maps_from_hs_fwd(const float* Hs, const float* U, int N, int H, int 
 int stabnet_interp_fwd(const float* im, const float* x, const float* y, int N, int H, int W, int C, float* out,
                        void* stream);
 
+/* ---- regressor building blocks -------------------------------------------------------------------------- */
+
+/* slim conv2d / conv2d_same (+ folded batch_norm + relu on the INPUT, + bias / residual / relu on the output):
+ * the op cluster of resnet_v2_50's bottleneck units called at s_net_bundle_nobm.py:252-253.
+ * x NHWC [N,H,W,Cin] (Cin % 16 == 0); w OHWI [Cout][KH][KW][Cin]; symmetric zero pad `pad`; y NHWC [N,Ho,Wo,Cout],
+ * Ho = (H + 2 pad - KH)/stride + 1.   A-operand prologue (both or neither): a = relu(a*in_scale[c] + in_shift[c]),
+ * applied to in-frame pixels only (padding stays 0).  Epilogue: + bias[n] (or NULL), + residual (or NULL; NHWC
+ * [N,res_H,res_W,Cout] read at (oy*res_stride, ox*res_stride) -- slim's `subsample` identity shortcut), relu if
+ * relu_out.  Arithmetic: exact float32 MFMA, fp32 accumulate.  workspace: stabnet_conv2d_workspace_bytes(). */
+size_t stabnet_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int stabnet_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, const float* in_scale,
+                       const float* in_shift, const float* residual, int res_H, int res_W, int res_stride, float* y,
+                       int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu_out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
