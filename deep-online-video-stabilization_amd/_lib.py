@@ -28,7 +28,7 @@ def declared_symbols(header_path: str = HEADER_PATH):
     txt = open(header_path).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     out = []
-    for m in re.finditer(r"^\s*(const char\s*\*|int|size_t|void)\s+(stabnet_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S | re.M):
+    for m in re.finditer(r"^\s*(const char\s*\*|int|size_t|void|double)\s+(stabnet_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S | re.M):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         argtypes = []
         args = " ".join(args.split())
@@ -40,7 +40,7 @@ def declared_symbols(header_path: str = HEADER_PATH):
                 else:
                     base = a.replace("const ", "").split()[0]
                     argtypes.append(_CTYPE[base])
-        restype = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "void": None}.get(ret, ctypes.c_char_p)
+        restype = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "void": None, "double": ctypes.c_double}.get(ret, ctypes.c_char_p)
         out.append((name, restype, argtypes))
     return out
 

@@ -1,0 +1,13 @@
+// Launchers of the non-convolution layers (layers.hip).
+#pragma once
+#include "common.h"
+
+int launch_pad_channels(const float* x, float* y, long npix, int C, int Cp, hipStream_t st);
+int launch_max_pool(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, int k, int stride, int pt,
+                    int pl, hipStream_t st);
+int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int G,
+                   float* scale, float* shift, hipStream_t st);
+int launch_gap_bn_relu(const float* x, const float* scale, const float* shift, int N, int HW, int C, float* out,
+                       hipStream_t st);
+int launch_fc(const float* x, const float* w, const float* b, float* y, int M, int K, int Nout, int relu,
+              hipStream_t st);

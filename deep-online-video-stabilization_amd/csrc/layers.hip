@@ -1,0 +1,160 @@
+// Small layers of the regressor (everything that is not a convolution), gfx950.  All HBM-bound elementwise /
+// reduction kernels: float4 accesses along the NHWC channel dimension.
+//   pad_channels   : x_tensor [N,H,W,13] -> [N,H,W,16] (zeros in the pad) so the stem runs on aligned 16-B pixels
+//   max_pool       : slim max_pool2d(3, stride 2, 'SAME')                       
+//   bn_fold        : moving-average BN -> per-channel (scale, shift)            tf.nn.batch_normalization form
+//   gap_bn_relu    : postnorm BN + ReLU + reduce_mean([1,2])                    s_net_bundle_nobm.py:254
+//   fc             : slim.fully_connected / output_layer for small batches      s_net_bundle_nobm.py:256-259, resnet.py:44-56
+#include "layers.h"
+
+__global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           long npix, int C, int Cp) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;      // one thread per (pixel, float4 of the padded pixel)
+    const int f4 = Cp / 4;
+    if (q >= npix * f4) return;
+    const long pix = q / f4;
+    const int c = (int)(q - pix * f4) * 4;
+    const float* s = x + pix * C;
+    float4 v;
+    v.x = (c + 0 < C) ? s[c + 0] : 0.f;
+    v.y = (c + 1 < C) ? s[c + 1] : 0.f;
+    v.z = (c + 2 < C) ? s[c + 2] : 0.f;
+    v.w = (c + 3 < C) ? s[c + 3] : 0.f;
+    *reinterpret_cast<float4*>(y + pix * Cp + c) = v;
+}
+
+__global__ __launch_bounds__(256) void max_pool_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H,
+                                                       int W, int C, int Ho, int Wo, int k, int stride, int pt, int pl) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = C / 4;
+    const long total = (long)N * Ho * Wo * c4n;
+    if (q >= total) return;
+    const int c = (int)(q % c4n) * 4;
+    long r = q / c4n;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int dy = 0; dy < k; ++dy) {
+        const int iy = oy * stride - pt + dy;
+        if (iy < 0 || iy >= H) continue;
+        for (int dx = 0; dx < k; ++dx) {
+            const int ix = ox * stride - pl + dx;
+            if (ix < 0 || ix >= W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(x + (((long)n * H + iy) * W + ix) * C + c);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    *reinterpret_cast<float4*>(y + (((long)n * Ho + oy) * Wo + ox) * C + c) = m;
+}
+
+// scale = rsqrt(var + eps) * gamma ; shift = beta - mean * scale       ([external] tf.nn.batch_normalization)
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ mean, const float* __restrict__ var,
+                                                      float eps, int G, float* __restrict__ scale,
+                                                      float* __restrict__ shift) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= G) return;
+    const float inv = (1.0f / sqrtf(var[i] + eps)) * gamma[i];
+    scale[i] = inv;
+    shift[i] = beta[i] - mean[i] * inv;
+}
+
+// out[n][c] = mean over (h,w) of relu(x*scale[c] + shift[c]).  block = 64 channels x 4 row groups; grid (C/64, N).
+__global__ __launch_bounds__(256) void gap_bn_relu_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int HW, int C,
+                                                          float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    const int n = blockIdx.y;
+    float s = 0.f;
+    if (c < C) {
+        const float sc = scale[c], sh = shift[c];
+        const float* p = x + (size_t)n * HW * C + c;
+        for (int i = g; i < HW; i += 4) s += fmaxf(p[(size_t)i * C] * sc + sh, 0.f);
+    }
+    part[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        const float t = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+        out[(size_t)n * C + c] = t / (float)HW;
+    }
+}
+
+// y[m][n] = act( sum_k x[m][k] * W[n][k] + b[n] ), M <= 16 rows per pass.  One wave per output channel n:
+// the weight row is streamed once (float4 per lane), the M activations rows come from L1/L2.
+template <int MR>
+__global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                 const float* __restrict__ b, float* __restrict__ y, int M, int K,
+                                                 int Nout, int relu, int m_begin) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= Nout) return;
+    float acc[MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) acc[i] = 0.f;
+    const float* wr = w + (size_t)n * K;
+    for (int k = lane * 4; k < K; k += 256) {
+        const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+            const int m = m_begin + i;
+            if (m < M) {
+                const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * K + k);
+                acc[i] += ((xv.x * wv.x + xv.y * wv.y) + xv.z * wv.z) + xv.w * wv.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        float v = acc[i];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        const int m = m_begin + i;
+        if (lane == 0 && m < M) {
+            v += (b != nullptr) ? b[n] : 0.f;
+            if (relu) v = fmaxf(v, 0.f);
+            y[(size_t)m * Nout + n] = v;
+        }
+    }
+}
+
+int launch_pad_channels(const float* x, float* y, long npix, int C, int Cp, hipStream_t st) {
+    SN_REQUIRE(Cp % 4 == 0 && Cp >= C, "pad_channels: bad channel counts %d -> %d", C, Cp);
+    pad_channels_kernel<<<cdiv(npix * (Cp / 4), 256), 256, 0, st>>>(x, y, npix, C, Cp);
+    SN_LAUNCH_CHECK("pad_channels_kernel");
+    return STABNET_OK;
+}
+
+int launch_max_pool(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, int k, int stride, int pt,
+                    int pl, hipStream_t st) {
+    SN_REQUIRE(C % 4 == 0, "max_pool: C %% 4 != 0");
+    max_pool_kernel<<<cdiv((long)N * Ho * Wo * (C / 4), 256), 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, k, stride, pt, pl);
+    SN_LAUNCH_CHECK("max_pool_kernel");
+    return STABNET_OK;
+}
+
+int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int G,
+                   float* scale, float* shift, hipStream_t st) {
+    bn_fold_kernel<<<cdiv(G, 256), 256, 0, st>>>(gamma, beta, mean, var, eps, G, scale, shift);
+    SN_LAUNCH_CHECK("bn_fold_kernel");
+    return STABNET_OK;
+}
+
+int launch_gap_bn_relu(const float* x, const float* scale, const float* shift, int N, int HW, int C, float* out,
+                       hipStream_t st) {
+    SN_REQUIRE(N <= 65535, "gap: N too large");
+    gap_bn_relu_kernel<<<dim3(cdiv(C, 64), N), 256, 0, st>>>(x, scale, shift, HW, C, out);
+    SN_LAUNCH_CHECK("gap_bn_relu_kernel");
+    return STABNET_OK;
+}
+
+int launch_fc(const float* x, const float* w, const float* b, float* y, int M, int K, int Nout, int relu,
+              hipStream_t st) {
+    SN_REQUIRE(K % 4 == 0, "fc: K %% 4 != 0");
+    for (int m0 = 0; m0 < M; m0 += 8) {
+        fc_kernel<8><<<cdiv(Nout, 4), 256, 0, st>>>(x, w, b, y, M, K, Nout, relu, m0);
+        SN_LAUNCH_CHECK("fc_kernel");
+    }
+    return STABNET_OK;
+}

@@ -1,0 +1,408 @@
+// The regressor as one host-side plan: slim resnet_v2_50 (global_pool=False, output_stride=32) -> reduce_mean ->
+// FC 2048/1024/512 (ReLU) -> output_layer, as built by get_resnet (s_net_bundle_nobm.py:250-264, resnet.py:44-56;
+// architecture: SURVEY.md Appendix A).  The plan owns NO device memory: parameters, folded BN, workspace and I/O
+// are caller buffers; a forward is one C call that only enqueues kernels (hipGraph-capturable).
+//
+// Parameter buffer layout (floats; every entry 16-B aligned), queried through stabnet_net_param_info():
+//   [conv weights OHWI (Cin padded to 16) / conv biases / FC weights [out][in] / FC biases, in network order]
+//   [all BN gammas][all BN betas]                      <- end of the trainable region
+//   [all BN moving means][all BN moving variances]     <- state region
+// The four BN sections share one channel ordering, so folding BN is a single elementwise kernel and the folded
+// (scale, shift) buffer is [G scales][G shifts].
+#include <string>
+#include <vector>
+#include <cstring>
+#include <algorithm>
+
+#include "conv.h"
+#include "layers.h"
+
+enum { PK_CONV_W = 0, PK_BIAS = 1, PK_GAMMA = 2, PK_BETA = 3, PK_MEAN = 4, PK_VAR = 5, PK_FC_W = 6, PK_FC_B = 7 };
+enum { S_PAD = 0, S_CONV = 1, S_POOL = 2, S_GAP = 3, S_FC = 4 };
+static const long EXT_IN = -2, EXT_OUT = -3, NONE = -1;
+
+struct ParamEntry {
+    std::string name;
+    int kind;
+    size_t off;
+    int dims[4];
+    int aux;   // conv: un-padded Cin
+};
+
+struct Step {
+    int kind;
+    ConvArgs conv;
+    long in_off, out_off, res_off, w_off, b_off, bn_off;
+    int N, H, W, C, Ho, Wo, k, stride, pt, pl;   // pool / pad / gap
+    int M, K, Nout, relu;                        // fc
+    size_t splitk_bytes;
+};
+
+struct Arena {                                    // first-fit free list over the activation workspace (floats)
+    struct Blk { size_t off, size; };
+    std::vector<Blk> free_;
+    size_t end = 0, peak = 0;
+    static size_t rnd(size_t n) { return (n + 63) & ~(size_t)63; }
+    size_t alloc(size_t n) {
+        n = rnd(n);
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].size >= n) {
+                const size_t o = free_[i].off;
+                free_[i].off += n;
+                free_[i].size -= n;
+                if (free_[i].size == 0) free_.erase(free_.begin() + i);
+                return o;
+            }
+        const size_t o = end;
+        end += n;
+        peak = std::max(peak, end);
+        return o;
+    }
+    void release(size_t off, size_t n) {
+        n = rnd(n);
+        free_.push_back({off, n});
+        std::sort(free_.begin(), free_.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+        for (size_t i = 0; i + 1 < free_.size();)
+            if (free_[i].off + free_[i].size == free_[i + 1].off) {
+                free_[i].size += free_[i + 1].size;
+                free_.erase(free_.begin() + i + 1);
+            } else
+                ++i;
+        if (!free_.empty() && free_.back().off + free_.back().size == end) {
+            end = free_.back().off;
+            free_.pop_back();
+        }
+    }
+};
+
+struct Net {
+    int N, H, W, in_ch, in_ch_pad, n_theta, keep_all;
+    std::vector<ParamEntry> params;
+    std::vector<ParamEntry> bn_entries[4];        // gamma, beta, mean, var (appended after the weights)
+    size_t n_floats = 0, n_trainable = 0, G = 0;
+    size_t off_gamma = 0, off_beta = 0, off_mean = 0, off_var = 0;
+    std::vector<Step> steps;
+    size_t act_floats = 0, splitk_bytes = 0;
+    double flops = 0;
+    int feat_H = 0, feat_W = 0;
+    struct Tap { std::string name; long off; int N, H, W, C; };
+    std::vector<Tap> taps;
+
+    size_t add_param(const std::string& name, int kind, int d0, int d1, int d2, int d3, int aux) {
+        ParamEntry e;
+        e.name = name; e.kind = kind; e.off = n_floats;
+        e.dims[0] = d0; e.dims[1] = d1; e.dims[2] = d2; e.dims[3] = d3; e.aux = aux;
+        size_t n = (size_t)d0 * std::max(d1, 1) * std::max(d2, 1) * std::max(d3, 1);
+        n_floats += (n + 3) & ~(size_t)3;
+        params.push_back(e);
+        return e.off;
+    }
+    long add_bn(const std::string& prefix, int C) {   // returns the channel offset inside the BN sections
+        const long off = (long)G;
+        const char* suffix[4] = {"/gamma", "/beta", "/moving_mean", "/moving_variance"};
+        for (int s = 0; s < 4; ++s) {
+            ParamEntry e;
+            e.name = prefix + suffix[s]; e.kind = PK_GAMMA + s; e.off = (size_t)off;   // section base added later
+            e.dims[0] = C; e.dims[1] = e.dims[2] = e.dims[3] = 0; e.aux = 0;
+            bn_entries[s].push_back(e);
+        }
+        G += (size_t)C;
+        return off;
+    }
+};
+
+struct TensorRef { long off; size_t size; int N, H, W, C; };
+
+static TensorRef new_tensor(Arena& ar, int N, int H, int W, int C) {
+    TensorRef t;
+    t.N = N; t.H = H; t.W = W; t.C = C;
+    t.size = (size_t)N * H * W * C;
+    t.off = (long)ar.alloc(t.size);
+    return t;
+}
+
+static void add_tap(Net& net, const std::string& name, const TensorRef& t) {
+    net.taps.push_back({name, t.off, t.N, t.H, t.W, t.C});
+}
+
+static void same_pads(int n, int k, int s, int& before, int& out) {
+    out = (n + s - 1) / s;
+    const int tot = std::max((out - 1) * s + k - n, 0);
+    before = tot / 2;
+}
+
+static Step conv_step(Net& net, const TensorRef& in, const TensorRef& out, int KH, int stride, int pad, long w_off,
+                      long b_off, long bn_off, const TensorRef* res, int res_stride, int real_cin = 0) {
+    Step s{};
+    s.kind = S_CONV;
+    ConvArgs& a = s.conv;
+    a.N = in.N; a.H = in.H; a.W = in.W; a.Cin = in.C; a.Cout = out.C; a.KH = KH; a.KW = KH; a.stride = stride; a.pad = pad;
+    a.up = 1; a.Ho = out.H; a.Wo = out.W;
+    a.res_H = res ? res->H : out.H; a.res_W = res ? res->W : out.W; a.res_stride = res ? res_stride : 1;
+    a.relu_out = 0;
+    s.splitk_bytes = conv_plan(a);
+    net.splitk_bytes = std::max(net.splitk_bytes, s.splitk_bytes);
+    s.in_off = in.off; s.out_off = out.off; s.res_off = res ? res->off : NONE;
+    s.w_off = w_off; s.b_off = b_off; s.bn_off = bn_off;
+    net.flops += 2.0 * a.M * (double)(a.KH * a.KW * (real_cin ? real_cin : a.Cin)) * a.Cout;   // algorithmic (un-padded)
+    return s;
+}
+
+static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all) {
+    Net* net = new Net();
+    net->N = N; net->H = H; net->W = W; net->in_ch = in_ch; net->n_theta = n_theta; net->keep_all = keep_all;
+    net->in_ch_pad = (in_ch + 15) / 16 * 16;
+    Arena ar;
+    auto done = [&](const TensorRef& t) { if (!keep_all) ar.release((size_t)t.off, t.size); };
+    const std::string R = "resnet_v2_50/";
+
+    // stem: conv2d_same(64, 7, stride 2) with bias, no BN/ReLU; then max_pool2d 3x3/2 SAME
+    TensorRef xin = new_tensor(ar, N, H, W, net->in_ch_pad);
+    {
+        Step s{};
+        s.kind = S_PAD; s.in_off = EXT_IN; s.out_off = xin.off; s.N = N; s.H = H; s.W = W; s.C = in_ch;
+        net->steps.push_back(s);
+    }
+    const int H1 = (H + 6 - 7) / 2 + 1, W1 = (W + 6 - 7) / 2 + 1;
+    TensorRef c1 = new_tensor(ar, N, H1, W1, 64);
+    {
+        const long w = (long)net->add_param(R + "conv1/weights", PK_CONV_W, 64, 7, 7, net->in_ch_pad, in_ch);
+        const long b = (long)net->add_param(R + "conv1/biases", PK_BIAS, 64, 0, 0, 0, 0);
+        net->steps.push_back(conv_step(*net, xin, c1, 7, 2, 3, w, b, NONE, nullptr, 1, in_ch));
+    }
+    done(xin);
+    add_tap(*net, "conv1", c1);
+    int pt, pl, H2, W2;
+    same_pads(H1, 3, 2, pt, H2);
+    same_pads(W1, 3, 2, pl, W2);
+    TensorRef cur = new_tensor(ar, N, H2, W2, 64);
+    {
+        Step s{};
+        s.kind = S_POOL; s.in_off = c1.off; s.out_off = cur.off;
+        s.N = N; s.H = H1; s.W = W1; s.C = 64; s.Ho = H2; s.Wo = W2; s.k = 3; s.stride = 2; s.pt = pt; s.pl = pl;
+        net->steps.push_back(s);
+    }
+    done(c1);
+    add_tap(*net, "pool1", cur);
+
+    struct Blk { const char* name; int depth, dbn, units, stride; };
+    const Blk blocks[4] = {{"block1", 256, 64, 3, 2}, {"block2", 512, 128, 4, 2}, {"block3", 1024, 256, 6, 2},
+                           {"block4", 2048, 512, 3, 1}};
+    for (const Blk& b : blocks) {
+        for (int u = 1; u <= b.units; ++u) {
+            const int stride = (u == b.units) ? b.stride : 1;
+            const std::string S = R + b.name + "/unit_" + std::to_string(u) + "/bottleneck_v2/";
+            const int cin = cur.C;
+            const long bn_pre = net->add_bn(S + "preact", cin);
+            const int Ho = (cur.H + 2 - 3) / stride + 1, Wo = (cur.W + 2 - 3) / stride + 1;
+            TensorRef sc = cur;
+            bool own_sc = false;
+            if (cin != b.depth) {       // projection shortcut: conv1x1(preact) + bias, stride 1 here
+                sc = new_tensor(ar, N, cur.H, cur.W, b.depth);
+                own_sc = true;
+                const long w = (long)net->add_param(S + "shortcut/weights", PK_CONV_W, b.depth, 1, 1, cin, cin);
+                const long bb = (long)net->add_param(S + "shortcut/biases", PK_BIAS, b.depth, 0, 0, 0, 0);
+                net->steps.push_back(conv_step(*net, cur, sc, 1, 1, 0, w, bb, bn_pre, nullptr, 1));
+            }
+            TensorRef r1 = new_tensor(ar, N, cur.H, cur.W, b.dbn);
+            {
+                const long w = (long)net->add_param(S + "conv1/weights", PK_CONV_W, b.dbn, 1, 1, cin, cin);
+                net->steps.push_back(conv_step(*net, cur, r1, 1, 1, 0, w, NONE, bn_pre, nullptr, 1));
+            }
+            const long bn1 = net->add_bn(S + "conv1/BatchNorm", b.dbn);
+            TensorRef r2 = new_tensor(ar, N, Ho, Wo, b.dbn);
+            {
+                const long w = (long)net->add_param(S + "conv2/weights", PK_CONV_W, b.dbn, 3, 3, b.dbn, b.dbn);
+                net->steps.push_back(conv_step(*net, r1, r2, 3, stride, 1, w, NONE, bn1, nullptr, 1));
+            }
+            done(r1);
+            const long bn2 = net->add_bn(S + "conv2/BatchNorm", b.dbn);
+            TensorRef nxt = new_tensor(ar, N, Ho, Wo, b.depth);
+            {
+                const long w = (long)net->add_param(S + "conv3/weights", PK_CONV_W, b.depth, 1, 1, b.dbn, b.dbn);
+                const long bb = (long)net->add_param(S + "conv3/biases", PK_BIAS, b.depth, 0, 0, 0, 0);
+                // identity shortcut of a strided unit = subsample(x, stride): read the residual at (oy*s, ox*s)
+                net->steps.push_back(conv_step(*net, r2, nxt, 1, 1, 0, w, bb, bn2, &sc, own_sc ? 1 : stride));
+            }
+            done(r2);
+            if (own_sc) done(sc);
+            done(cur);
+            cur = nxt;
+            add_tap(*net, std::string(b.name) + "/unit_" + std::to_string(u), cur);
+        }
+    }
+    net->feat_H = cur.H; net->feat_W = cur.W;
+    const long bn_post = net->add_bn(R + "postnorm", cur.C);
+    TensorRef g = new_tensor(ar, N, 1, 1, cur.C);
+    {
+        Step s{};
+        s.kind = S_GAP; s.in_off = cur.off; s.out_off = g.off; s.bn_off = bn_post; s.N = N; s.H = cur.H; s.W = cur.W; s.C = cur.C;
+        net->steps.push_back(s);
+    }
+    done(cur);
+    add_tap(*net, "global_pool", g);
+    const int dims[4] = {cur.C, 2048, 1024, 512};
+    TensorRef f = g;
+    for (int k = 1; k <= 3; ++k) {
+        TensorRef o = new_tensor(ar, N, 1, 1, dims[k]);
+        Step s{};
+        s.kind = S_FC; s.in_off = f.off; s.out_off = o.off; s.M = N; s.K = dims[k - 1]; s.Nout = dims[k]; s.relu = 1;
+        s.w_off = (long)net->add_param("fc/fc/fc_" + std::to_string(k) + "/weights", PK_FC_W, dims[k], dims[k - 1], 0, 0, 0);
+        s.b_off = (long)net->add_param("fc/fc/fc_" + std::to_string(k) + "/biases", PK_FC_B, dims[k], 0, 0, 0, 0);
+        net->steps.push_back(s);
+        net->flops += 2.0 * N * dims[k - 1] * dims[k];
+        done(f);
+        f = o;
+    }
+    {
+        Step s{};
+        s.kind = S_FC; s.in_off = f.off; s.out_off = EXT_OUT; s.M = N; s.K = 512; s.Nout = n_theta; s.relu = 0;
+        s.w_off = (long)net->add_param("fc/fc_weights", PK_FC_W, n_theta, 512, 0, 0, 0);
+        s.b_off = (long)net->add_param("fc/fc_bias", PK_FC_B, n_theta, 0, 0, 0, 0);
+        net->steps.push_back(s);
+        net->flops += 2.0 * N * 512 * n_theta;
+    }
+    // BN sections
+    net->off_gamma = net->n_floats;
+    net->off_beta = net->off_gamma + net->G;
+    net->n_trainable = net->off_beta + net->G;
+    net->off_mean = net->n_trainable;
+    net->off_var = net->off_mean + net->G;
+    net->n_floats = net->off_var + net->G;
+    const size_t base[4] = {net->off_gamma, net->off_beta, net->off_mean, net->off_var};
+    for (int s = 0; s < 4; ++s)
+        for (ParamEntry e : net->bn_entries[s]) {
+            e.off += base[s];
+            net->params.push_back(e);
+        }
+    net->act_floats = ar.peak;
+    return net;
+}
+
+static int run_forward(const Net* net, const float* params, const float* fold, const float* x, float* theta,
+                       float* ws, hipStream_t st) {
+    float* splitk = ws + net->act_floats;
+    const float* scale = fold;
+    const float* shift = fold + net->G;
+    for (const Step& s : net->steps) {
+        int rc = STABNET_OK;
+        switch (s.kind) {
+            case S_PAD:
+                rc = launch_pad_channels(x, ws + s.out_off, (long)s.N * s.H * s.W, s.C, net->in_ch_pad, st);
+                break;
+            case S_CONV: {
+                ConvArgs a = s.conv;
+                a.x = ws + s.in_off;
+                a.y = ws + s.out_off;
+                a.w = params + s.w_off;
+                a.bias = s.b_off >= 0 ? params + s.b_off : nullptr;
+                a.residual = s.res_off >= 0 ? ws + s.res_off : nullptr;
+                a.in_scale = s.bn_off >= 0 ? scale + s.bn_off : nullptr;
+                a.in_shift = s.bn_off >= 0 ? shift + s.bn_off : nullptr;
+                a.partial = splitk;
+                rc = conv_launch(a, st);
+                break;
+            }
+            case S_POOL:
+                rc = launch_max_pool(ws + s.in_off, ws + s.out_off, s.N, s.H, s.W, s.C, s.Ho, s.Wo, s.k, s.stride, s.pt,
+                                     s.pl, st);
+                break;
+            case S_GAP:
+                rc = launch_gap_bn_relu(ws + s.in_off, scale + s.bn_off, shift + s.bn_off, s.N, s.H * s.W, s.C,
+                                        ws + s.out_off, st);
+                break;
+            case S_FC:
+                rc = launch_fc(ws + s.in_off, params + s.w_off, params + s.b_off,
+                               s.out_off == EXT_OUT ? theta : ws + s.out_off, s.M, s.K, s.Nout, s.relu, st);
+                break;
+        }
+        if (rc) return rc;
+    }
+    return STABNET_OK;
+}
+
+extern "C" {
+
+int stabnet_net_create(void** out, int N, int H, int W, int in_ch, int n_theta, int keep_activations) {
+    SN_REQUIRE(out != nullptr, "net_create: null out");
+    SN_REQUIRE(N > 0 && N <= 4096 && H >= 32 && W >= 32 && in_ch > 0 && in_ch <= 64 && n_theta > 0,
+               "net_create: bad shape N=%d H=%d W=%d in_ch=%d n_theta=%d (H,W >= 32)", N, H, W, in_ch, n_theta);
+    *out = build_net(N, H, W, in_ch, n_theta, keep_activations);
+    return STABNET_OK;
+}
+
+void stabnet_net_destroy(void* net) { delete static_cast<Net*>(net); }
+
+int stabnet_net_num_params(const void* net) { return net ? (int)static_cast<const Net*>(net)->params.size() : -1; }
+
+/* kind: 0 conv weight (dims Cout,KH,KW,CinPadded; aux = real Cin), 1 conv bias, 2 gamma, 3 beta, 4 moving_mean,
+ * 5 moving_variance, 6 FC weight (dims out,in), 7 FC bias. */
+int stabnet_net_param_info(const void* netp, int idx, char* name, int name_cap, long* offset, int* kind, int* dims4,
+                           int* aux) {
+    const Net* net = static_cast<const Net*>(netp);
+    SN_REQUIRE(net && idx >= 0 && idx < (int)net->params.size(), "param_info: bad index %d", idx);
+    const ParamEntry& e = net->params[idx];
+    if (name && name_cap > 0) {
+        std::strncpy(name, e.name.c_str(), (size_t)name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (offset) *offset = (long)e.off;
+    if (kind) *kind = e.kind;
+    if (dims4) for (int i = 0; i < 4; ++i) dims4[i] = e.dims[i];
+    if (aux) *aux = e.aux;
+    return STABNET_OK;
+}
+
+size_t stabnet_net_param_floats(const void* net) { return net ? static_cast<const Net*>(net)->n_floats : 0; }
+size_t stabnet_net_trainable_floats(const void* net) { return net ? static_cast<const Net*>(net)->n_trainable : 0; }
+size_t stabnet_net_bn_channels(const void* net) { return net ? static_cast<const Net*>(net)->G : 0; }
+size_t stabnet_net_workspace_bytes(const void* netp) {
+    const Net* net = static_cast<const Net*>(netp);
+    return net ? net->act_floats * sizeof(float) + net->splitk_bytes + 256 : 0;
+}
+double stabnet_net_flops(const void* net) { return net ? static_cast<const Net*>(net)->flops : 0.0; }
+int stabnet_net_num_launches(const void* netp) {
+    const Net* net = static_cast<const Net*>(netp);
+    if (!net) return -1;
+    int n = 0;
+    for (const Step& s : net->steps) n += (s.kind == S_CONV && s.conv.splitk > 1) ? 2 : (s.kind == S_FC ? (s.M + 7) / 8 : 1);
+    return n;
+}
+
+/* Debug taps (valid after a forward only when the net was created with keep_activations=1):
+ * names conv1, pool1, block{1-4}/unit_{k}, global_pool -> float offset into the workspace and NHWC dims. */
+int stabnet_net_activation_info(const void* netp, const char* name, long* offset, int* dims4) {
+    const Net* net = static_cast<const Net*>(netp);
+    SN_REQUIRE(net && name && offset && dims4, "activation_info: null pointer");
+    for (const Net::Tap& t : net->taps)
+        if (t.name == name) {
+            *offset = t.off;
+            dims4[0] = t.N; dims4[1] = t.H; dims4[2] = t.W; dims4[3] = t.C;
+            return STABNET_OK;
+        }
+    stabnet_set_error("activation_info: no tap named %s", name);
+    return STABNET_ERR_BAD_ARG;
+}
+
+/* Moving-average BN -> folded (scale, shift): fold = [G scales][G shifts].  Run once after loading weights. */
+int stabnet_net_fold_bn(const void* netp, const float* params, float* fold, float eps, void* stream) {
+    const Net* net = static_cast<const Net*>(netp);
+    SN_REQUIRE(net && params && fold, "fold_bn: null pointer");
+    return launch_bn_fold(params + net->off_gamma, params + net->off_beta, params + net->off_mean,
+                          params + net->off_var, eps, (int)net->G, fold, fold + net->G, (hipStream_t)stream);
+}
+
+/* get_resnet(x_tensor, is_training=False): x_tensor NHWC [N,H,W,in_ch] -> theta [N,n_theta]. */
+int stabnet_backbone_fwd_infer(const void* netp, const float* params, const float* fold, const float* x_tensor,
+                               float* theta, void* workspace, size_t workspace_bytes, void* stream) {
+    const Net* net = static_cast<const Net*>(netp);
+    SN_REQUIRE(net && params && fold && x_tensor && theta && workspace, "backbone_fwd_infer: null pointer");
+    if (workspace_bytes < stabnet_net_workspace_bytes(netp)) {
+        stabnet_set_error("backbone_fwd_infer: workspace %zu B < %zu B needed", workspace_bytes,
+                          stabnet_net_workspace_bytes(netp));
+        return STABNET_ERR_WORKSPACE;
+    }
+    return run_forward(net, params, fold, x_tensor, theta, static_cast<float*>(workspace), (hipStream_t)stream);
+}
+
+}  // extern "C"

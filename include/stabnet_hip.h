@@ -72,6 +72,38 @@ int stabnet_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, c
                        int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu_out,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- the regressor as one plan --------------------------------------------------------------------------
+ * get_resnet(x_tensor, reuse, is_training=False, x_batch_size) -> theta       s_net_bundle_nobm.py:250-264
+ *   = slim resnet_v2_50(global_pool=False, output_stride=32) -> reduce_mean([1,2]) -> fully_connected 2048/1024/512
+ *     -> output_layer (resnet.py:44-56).  The run-time feed/fetch it serves: x_tensor:0 -> (theta ->) the tensors of
+ *     deploy_bundle.py:48-56,286.
+ * A net handle is a HOST-ONLY description (layer list, buffer offsets); it owns no device memory.
+ * Parameter buffer (floats): [weights/biases in network order][BN gammas][BN betas] | [moving means][moving vars];
+ * the first stabnet_net_trainable_floats() floats are the trainables.  Conv weights are OHWI with Cin padded to 16,
+ * FC weights [out][in]; stabnet_net_param_info() gives name (TF variable name under stable_net/resnet/), offset,
+ * kind (0 conv w, 1 conv bias, 2 gamma, 3 beta, 4 moving_mean, 5 moving_variance, 6 FC w, 7 FC bias), dims, aux
+ * (conv: un-padded Cin). */
+int stabnet_net_create(void** net, int N, int H, int W, int in_ch, int n_theta, int keep_activations);
+void stabnet_net_destroy(void* net);
+int stabnet_net_num_params(const void* net);
+int stabnet_net_param_info(const void* net, int idx, char* name, int name_cap, long* offset, int* kind, int* dims4,
+                           int* aux);
+size_t stabnet_net_param_floats(const void* net);
+size_t stabnet_net_trainable_floats(const void* net);
+size_t stabnet_net_bn_channels(const void* net);
+size_t stabnet_net_workspace_bytes(const void* net);
+double stabnet_net_flops(const void* net);
+int stabnet_net_num_launches(const void* net);
+int stabnet_net_activation_info(const void* net, const char* name, long* offset, int* dims4);
+
+/* slim batch_norm(is_training=False) folded to per-channel (scale, shift): fold = [G scales][G shifts],
+ * G = stabnet_net_bn_channels().  scale = rsqrt(var + eps) * gamma, shift = beta - mean * scale. */
+int stabnet_net_fold_bn(const void* net, const float* params, float* fold, float eps, void* stream);
+
+/* x_tensor NHWC [N,H,W,in_ch] -> theta [N,n_theta]; BN in moving-average mode (s_net_bundle_nobm.py:302). */
+int stabnet_backbone_fwd_infer(const void* net, const float* params, const float* fold, const float* x_tensor,
+                               float* theta, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
