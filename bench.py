@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: stabilised frames/s of the StabNet hot path on MI355X (BASELINE.json configs[1]).
+
+A step = one output frame of one online stream: 13-channel stack assembled from the on-device history ring ->
+ResNet-v2-50 regressor -> mesh -> multi-grid warp -> feedback push.  Frames of a stream are serially dependent
+(deploy_bundle.py:322-323), so N GPUs = N independent streams (replicas, no collective): weak scaling.
+Inputs (the synthetic 720p clip) are resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--streams", type=int, default=1, help="streams per GPU stepped in lock-step (batch of the net)")
+    ap.add_argument("--before-ch", type=int, default=31, help="accepted and ignored, as in deploy_bundle.py:15,41")
+    ap.add_argument("--refine", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--clip-frames", type=int, default=32)
+    return ap.parse_args()
+
+
+def roofline_from_records(recs, steps):
+    """recs: [(kernel, ms, flops, bytes)] over `steps` instrumented frames -> (roofline dict, per-kernel table)."""
+    agg = {}
+    for name, ms, fl, by in recs:
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += ms
+        a[2] += fl
+        a[3] += by
+    table = []
+    for name, (n, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        table.append({"kernel": name, "launches_per_frame": n / steps, "avg_us": 1e3 * ms / n,
+                      "ms_per_frame": ms / steps, "tflops": (fl / (ms * 1e-3) / 1e12) if fl else None,
+                      "gbps": by / (ms * 1e-3) / 1e9})
+    dom = table[0]
+    name = dom["kernel"]
+    n, ms, fl, by = agg[name]
+    if fl > 0:
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_us": 1e3 * ms / n,
+                "algorithmic_flops_per_launch": fl / n}
+    else:
+        ach = by / (ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                "frac": ach / PEAK_HBM_GBPS, "traffic": None, "avg_launch_us": 1e3 * ms / n,
+                "algorithmic_bytes_per_launch": by / n}
+    return roof, table
+
+
+def cpu_baseline(P, clip, H, W, budget_s):
+    """The oracle (NumPy restatement of the reference, 'port') timed on this box's host cores on a bounded sample."""
+    from oracle import stabnet_oracle as O
+    ocfg = O.Config(height=H, width=W)
+    ring = O.DeployRing(clip[0], ocfg)
+    t0 = time.time()
+    n = 0
+    while True:
+        O.deploy_step(ring, clip[1 + n % (len(clip) - 1)], P, ocfg)
+        n += 1
+        el = time.time() - t0
+        if n >= 2 and (el >= budget_s or el / n * (n + 1) > 1.5 * budget_s):
+            break
+        if n == 1 and el > budget_s:
+            break
+    el = time.time() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([d.get("num_threads", 1) for d in threadpool_info()] + [1])
+    except Exception:
+        thr = os.cpu_count()
+    return {"value": n / el, "unit": "frames/s", "cores": thr, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "%d sequential %dx%d frames of the same synthetic clip through oracle.deploy_step "
+                      "(NumPy/OpenBLAS restatement; the TF1 reference cannot run offline)" % (n, W, H)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from stabnet_amd import synthetic
+    from stabnet_amd.config import Config
+    from stabnet_amd.deploy import Profiler, StabNetStream
+
+    H, W, S = args.height, args.width, args.streams
+    cfg = Config(height=H, width=W)
+    P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
+    clip = synthetic.make_clip(H, W, args.clip_frames, seed=1234 + rank)
+    clip_dev = torch.from_numpy(clip).to(dev)                      # resident in HBM before timing
+    frames = [clip_dev[t:t + 1].expand(S, H, W).contiguous() for t in range(args.clip_frames)]
+    stream = StabNetStream(P, H, W, cfg, streams=S, device=dev, refine=args.refine, before_ch=args.before_ch)
+    stream.start(frames[0])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t = 1
+    for _ in range(args.warmup):
+        stream.step(frames[t % args.clip_frames])
+        t += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stream.step(frames[t % args.clip_frames])
+        t += 1
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    barrier()
+    checksum = float(stream.out_img.double().sum().item())
+
+    roof, table, prof_ms = None, None, None
+    if rank == 0 and not args.no_roofline:
+        # the same K steps again with an event pair around every launch (instrumentation kept out of `value`)
+        prof = Profiler(max_records=args.steps * (stream.reg.plan.num_launches + 16))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            stream.step(frames[t % args.clip_frames], prof)
+            t += 1
+        torch.cuda.synchronize()
+        prof_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        roof, table = roofline_from_records(prof.records(), args.steps)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(P, clip, H, W, args.cpu_baseline_seconds)
+
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        fps = args.steps * S * world / el
+        line = {
+            "metric": "stabilized frames/sec (720p, before_ch=31)" if (H, W) == (720, 1280) else
+                      "stabilized frames/sec (%dx%d)" % (W, H),
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: v2_93 net, %dx%d, %d stream(s)/GPU, batch=1 per stream, "
+                                   "13-ch stack from a 32-deep ring (lags 1,2,4,8,16,32; --before-ch %d ignored as in "
+                                   "the reference), ResNet-v2-50 regressor + 4x4 multi-grid warp + feedback; one "
+                                   "independent stream set per GPU (replicas only)" % (W, H, S, args.before_ch),
+                       "height": H, "width": W, "streams_per_gpu": S, "refine": args.refine,
+                       "backbone_gflop_per_frame": stream.reg.plan.flops / 1e9 / S,
+                       "launches_per_frame": stream.reg.plan.num_launches + 4},
+            "per_gpu_fps": fps / world, "checksum": checksum,
+        }
+        if roof is not None:
+            line["roofline"] = roof
+            line["kernels"] = table[:8]
+            line["instrumented_ms_per_step"] = prof_ms
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

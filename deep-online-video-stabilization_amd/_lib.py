@@ -6,6 +6,10 @@ import ctypes
 import os
 import re
 
+# torch bundles its own HIP runtime (libamdhip64.so.7, same SONAME as /opt/rocm's).  Import it BEFORE loading the
+# library so the process has exactly one runtime -- the one that owns torch's device memory and streams.
+import torch  # noqa: F401  (plumbing: device memory, streams)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstabnet_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "stabnet_hip.h")

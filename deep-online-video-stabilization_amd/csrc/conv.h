@@ -19,9 +19,11 @@ struct ConvArgs {
     int relu_out;
     int M, K;                // M = N*Ho*Wo, K = KH*KW*Cin
     int splitk, steps_per_split;
+    int cin_real;            // un-padded Cin (algorithmic flop accounting only); 0 = Cin
 };
 
 // Chooses tile shape / split-K and returns the workspace bytes the launch needs (0 if none).
 size_t conv_plan(ConvArgs& a);
 // Enqueues the convolution (and the split-K reduction when a.splitk > 1).
-int conv_launch(const ConvArgs& a, hipStream_t st);
+struct Prof;
+int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof = nullptr);

@@ -14,6 +14,7 @@
 // Global->LDS staging goes through registers (the BN+ReLU prologue and the im2col zero padding need the VALU),
 // issued one K-step ahead of the MFMAs (double-buffered LDS, one barrier per K-step).
 #include "conv.h"
+#include "prof.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -298,7 +299,7 @@ static int launch_one(const ConvArgs& a, hipStream_t st) {
     return STABNET_OK;
 }
 
-int conv_launch(const ConvArgs& a, hipStream_t st) {
+int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof) {
     SN_REQUIRE(a.Cin % 16 == 0, "conv: Cin=%d must be a multiple of 16 (pad the channels)", a.Cin);
     SN_REQUIRE(a.splitk >= 1 && a.steps_per_split >= 1, "conv: conv_plan() not called");
     SN_REQUIRE(a.splitk == 1 || a.partial != nullptr, "conv: split-K needs a workspace");
@@ -306,6 +307,7 @@ int conv_launch(const ConvArgs& a, hipStream_t st) {
     const int t = pick_tile(a, splitk_unused);
     const bool bk32 = (a.Cin % 32 == 0);
     int rc;
+    const bool rec = prof != nullptr && prof->begin(st);
     if (bk32) {
         if (t == T128x128) rc = launch_one<128, 128, 32, 64, 64>(a, st);
         else if (t == T128x64) rc = launch_one<128, 64, 32, 64, 32>(a, st);
@@ -315,10 +317,15 @@ int conv_launch(const ConvArgs& a, hipStream_t st) {
         else if (t == T128x64) rc = launch_one<128, 64, 16, 64, 32>(a, st);
         else rc = launch_one<64, 64, 16, 32, 32>(a, st);
     }
+    if (rec) prof->end(st, PK_KERNEL_CONV_BASE + t * 2 + (bk32 ? 1 : 0), 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
+                       4.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.K * a.Cout + (double)a.M * a.Cout * a.splitk),
+                       a.M, a.Cout, a.K, a.splitk);
     if (rc) return rc;
     if (a.splitk > 1) {
         const size_t q = (size_t)a.M * (a.Cout / 4);
+        const bool rec2 = prof != nullptr && prof->begin(st);
         conv_splitk_reduce_kernel<<<cdiv((long)q, 256), 256, 0, st>>>(a);
+        if (rec2) prof->end(st, PK_KERNEL_SPLITK_REDUCE, 0.0, 4.0 * (double)a.M * a.Cout * (a.splitk + 1));
         SN_LAUNCH_CHECK("conv_splitk_reduce_kernel");
     }
     return STABNET_OK;

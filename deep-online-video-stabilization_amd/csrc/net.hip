@@ -16,6 +16,9 @@
 
 #include "conv.h"
 #include "layers.h"
+#include "prof.h"
+#include "ring.h"
+#include "warp.h"
 
 enum { PK_CONV_W = 0, PK_BIAS = 1, PK_GAMMA = 2, PK_BETA = 3, PK_MEAN = 4, PK_VAR = 5, PK_FC_W = 6, PK_FC_B = 7 };
 enum { S_PAD = 0, S_CONV = 1, S_POOL = 2, S_GAP = 3, S_FC = 4 };
@@ -140,6 +143,7 @@ static Step conv_step(Net& net, const TensorRef& in, const TensorRef& out, int K
     a.up = 1; a.Ho = out.H; a.Wo = out.W;
     a.res_H = res ? res->H : out.H; a.res_W = res ? res->W : out.W; a.res_stride = res ? res_stride : 1;
     a.relu_out = 0;
+    a.cin_real = real_cin ? real_cin : in.C;
     s.splitk_bytes = conv_plan(a);
     net.splitk_bytes = std::max(net.splitk_bytes, s.splitk_bytes);
     s.in_off = in.off; s.out_off = out.off; s.res_off = res ? res->off : NONE;
@@ -280,12 +284,14 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
 }
 
 static int run_forward(const Net* net, const float* params, const float* fold, const float* x, float* theta,
-                       float* ws, hipStream_t st) {
+                       float* ws, hipStream_t st, Prof* prof = nullptr, bool skip_pad = false) {
     float* splitk = ws + net->act_floats;
     const float* scale = fold;
     const float* shift = fold + net->G;
     for (const Step& s : net->steps) {
         int rc = STABNET_OK;
+        if (s.kind == S_PAD && skip_pad) continue;
+        const bool rec = (s.kind != S_CONV) && prof != nullptr && prof->begin(st);
         switch (s.kind) {
             case S_PAD:
                 rc = launch_pad_channels(x, ws + s.out_off, (long)s.N * s.H * s.W, s.C, net->in_ch_pad, st);
@@ -300,7 +306,7 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
                 a.in_scale = s.bn_off >= 0 ? scale + s.bn_off : nullptr;
                 a.in_shift = s.bn_off >= 0 ? shift + s.bn_off : nullptr;
                 a.partial = splitk;
-                rc = conv_launch(a, st);
+                rc = conv_launch(a, st, prof);
                 break;
             }
             case S_POOL:
@@ -316,12 +322,88 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
                                s.out_off == EXT_OUT ? theta : ws + s.out_off, s.M, s.K, s.Nout, s.relu, st);
                 break;
         }
+        if (rec) {
+            static const int kmap[5] = {PK_KERNEL_PAD, 0, PK_KERNEL_POOL, PK_KERNEL_GAP, PK_KERNEL_FC};
+            double bytes = 0;
+            if (s.kind == S_PAD) bytes = 4.0 * s.N * s.H * s.W * (s.C + net->in_ch_pad);
+            if (s.kind == S_POOL) bytes = 4.0 * s.N * s.C * ((double)s.H * s.W + (double)s.Ho * s.Wo);
+            if (s.kind == S_GAP) bytes = 4.0 * s.N * s.C * ((double)s.H * s.W + 1);
+            if (s.kind == S_FC) bytes = 4.0 * ((double)s.K * s.Nout + (double)s.M * (s.K + s.Nout));
+            prof->end(st, kmap[s.kind], s.kind == S_FC ? 2.0 * s.M * s.K * s.Nout : 0.0, bytes);
+        }
         if (rc) return rc;
     }
     return STABNET_OK;
 }
 
 extern "C" {
+
+int stabnet_prof_create(void** out, int max_records) {
+    SN_REQUIRE(out && max_records > 0 && max_records <= (1 << 20), "prof_create: bad arguments");
+    Prof* p = new Prof();
+    p->cap = max_records;
+    p->ev.resize(2 * (size_t)max_records);
+    p->kind.resize(max_records); p->flops.resize(max_records); p->bytes.resize(max_records);
+    p->shape.resize(4 * (size_t)max_records);
+    for (auto& e : p->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            stabnet_set_error("prof_create: hipEventCreate failed");
+            return STABNET_ERR_LAUNCH;
+        }
+    *out = p;
+    return STABNET_OK;
+}
+void stabnet_prof_destroy(void* pp) {
+    Prof* p = static_cast<Prof*>(pp);
+    if (!p) return;
+    for (auto& e : p->ev) (void)hipEventDestroy(e);
+    delete p;
+}
+int stabnet_prof_reset(void* pp) {
+    SN_REQUIRE(pp, "prof_reset: null");
+    static_cast<Prof*>(pp)->n = 0;
+    return STABNET_OK;
+}
+int stabnet_prof_num_records(const void* pp) { return pp ? static_cast<const Prof*>(pp)->n : -1; }
+/* The stream the records were taken on must have been synchronised by the caller. */
+int stabnet_prof_record(const void* pp, int idx, int* kind, float* ms, double* flops, double* bytes) {
+    const Prof* p = static_cast<const Prof*>(pp);
+    SN_REQUIRE(p && idx >= 0 && idx < p->n && kind && ms && flops && bytes, "prof_record: bad arguments");
+    hipError_t e = hipEventElapsedTime(ms, p->ev[2 * idx], p->ev[2 * idx + 1]);
+    if (e != hipSuccess) {
+        stabnet_set_error("prof_record: %s", hipGetErrorString(e));
+        return STABNET_ERR_LAUNCH;
+    }
+    *kind = p->kind[idx]; *flops = p->flops[idx]; *bytes = p->bytes[idx];
+    return STABNET_OK;
+}
+/* GEMM view of a record: shape4 = {M, N, K, split-K}; zeros for non-GEMM kernels. */
+int stabnet_prof_record_shape(const void* pp, int idx, int* shape4) {
+    const Prof* p = static_cast<const Prof*>(pp);
+    SN_REQUIRE(p && idx >= 0 && idx < p->n && shape4, "prof_record_shape: bad arguments");
+    for (int i = 0; i < 4; ++i) shape4[i] = p->shape[4 * idx + i];
+    return STABNET_OK;
+}
+const char* stabnet_prof_kind_name(int kind) {
+    switch (kind) {
+        case PK_KERNEL_PAD: return "pad_channels_kernel";
+        case PK_KERNEL_POOL: return "max_pool_kernel";
+        case PK_KERNEL_GAP: return "gap_bn_relu_kernel";
+        case PK_KERNEL_FC: return "fc_kernel";
+        case PK_KERNEL_MESH: return "mesh_homography_kernel";
+        case PK_KERNEL_WARP: return "warp_sample_kernel";
+        case PK_KERNEL_ASSEMBLE: return "stack_assemble_kernel";
+        case PK_KERNEL_PUSH: return "ring_push_kernel";
+        case PK_KERNEL_SPLITK_REDUCE: return "conv_splitk_reduce_kernel";
+        case PK_KERNEL_CONV_BASE + 0: return "conv_igemm_f32_kernel<128,128,16,64,64>";
+        case PK_KERNEL_CONV_BASE + 1: return "conv_igemm_f32_kernel<128,128,32,64,64>";
+        case PK_KERNEL_CONV_BASE + 2: return "conv_igemm_f32_kernel<128,64,16,64,32>";
+        case PK_KERNEL_CONV_BASE + 3: return "conv_igemm_f32_kernel<128,64,32,64,32>";
+        case PK_KERNEL_CONV_BASE + 4: return "conv_igemm_f32_kernel<64,64,16,32,32>";
+        case PK_KERNEL_CONV_BASE + 5: return "conv_igemm_f32_kernel<64,64,32,32,32>";
+    }
+    return "?";
+}
 
 int stabnet_net_create(void** out, int N, int H, int W, int in_ch, int n_theta, int keep_activations) {
     SN_REQUIRE(out != nullptr, "net_create: null out");
@@ -394,7 +476,7 @@ int stabnet_net_fold_bn(const void* netp, const float* params, float* fold, floa
 
 /* get_resnet(x_tensor, is_training=False): x_tensor NHWC [N,H,W,in_ch] -> theta [N,n_theta]. */
 int stabnet_backbone_fwd_infer(const void* netp, const float* params, const float* fold, const float* x_tensor,
-                               float* theta, void* workspace, size_t workspace_bytes, void* stream) {
+                               float* theta, void* workspace, size_t workspace_bytes, void* stream, void* prof) {
     const Net* net = static_cast<const Net*>(netp);
     SN_REQUIRE(net && params && fold && x_tensor && theta && workspace, "backbone_fwd_infer: null pointer");
     if (workspace_bytes < stabnet_net_workspace_bytes(netp)) {
@@ -402,7 +484,79 @@ int stabnet_backbone_fwd_infer(const void* netp, const float* params, const floa
                           stabnet_net_workspace_bytes(netp));
         return STABNET_ERR_WORKSPACE;
     }
-    return run_forward(net, params, fold, x_tensor, theta, static_cast<float*>(workspace), (hipStream_t)stream);
+    return run_forward(net, params, fold, x_tensor, theta, static_cast<float*>(workspace), (hipStream_t)stream,
+                       static_cast<Prof*>(prof));
+}
+
+/* History ring initialisation: `depth` copies of the first frame, zero masks (deploy_bundle.py:216-224). */
+int stabnet_ring_init(float* frames_ring, float* masks_ring, const float* first_frame, int S, int depth, int H, int W,
+                      void* stream) {
+    SN_REQUIRE(frames_ring && masks_ring && first_frame && S > 0 && S <= 65535 && depth > 0 && H > 0 && W > 0,
+               "ring_init: bad arguments");
+    return launch_ring_init(frames_ring, masks_ring, first_frame, S, depth, (long)H * W, (hipStream_t)stream);
+}
+
+/* One iteration of the online loop for S = net.N independent streams (deploy_bundle.py:259-296,319-332):
+ * stack assembly from the ring -> regressor -> get_4_pts + transformer -> frame = img - black -> push.
+ * `head` = ring slot this frame's push writes (caller advances it: head = (head+1) % depth).  `lags` is a HOST array. */
+int stabnet_deploy_frame(const void* netp, const float* params, const float* fold, float* frames_ring,
+                         float* masks_ring, int depth, int head, const int* lags, int n_lags, const float* cur_frame,
+                         int refine, int grid_h, int grid_w, float do_crop_rate, float* theta, float* out_img,
+                         float* black, float* x_map, float* y_map, float* Hs, float* frame_fb, void* workspace,
+                         size_t workspace_bytes, void* stream, void* profp) {
+    const Net* net = static_cast<const Net*>(netp);
+    SN_REQUIRE(net && params && fold && frames_ring && masks_ring && lags && cur_frame && theta && out_img && black &&
+                   x_map && y_map && Hs && frame_fb && workspace, "deploy_frame: null pointer");
+    SN_REQUIRE(depth > 0 && head >= 0 && head < depth && refine >= 1, "deploy_frame: bad ring arguments");
+    SN_REQUIRE(2 * n_lags + 1 == net->in_ch && n_lags <= 7, "deploy_frame: %d lags do not make %d channels", n_lags,
+               net->in_ch);
+    SN_REQUIRE((grid_h + 1) * (grid_w + 1) * 2 == net->n_theta, "deploy_frame: grid does not match n_theta");
+    if (workspace_bytes < stabnet_net_workspace_bytes(netp)) {
+        stabnet_set_error("deploy_frame: workspace %zu B < %zu B needed", workspace_bytes, stabnet_net_workspace_bytes(netp));
+        return STABNET_ERR_WORKSPACE;
+    }
+    int rc = check_warp_args(net->N, net->H, net->W, 1, grid_h, grid_w);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    Prof* prof = static_cast<Prof*>(profp);
+    float* ws = static_cast<float*>(workspace);
+    RingLags rl{};
+    rl.n = n_lags;
+    for (int i = 0; i < n_lags; ++i) {
+        SN_REQUIRE(lags[i] > 0 && lags[i] <= depth, "deploy_frame: lag %d outside the ring", lags[i]);
+        rl.lag[i] = lags[i];
+    }
+    const long hw = (long)net->H * net->W;
+    const float* cur = cur_frame;
+    float* x16 = ws + net->steps[0].out_off;
+    for (int j = 0; j < refine; ++j) {
+        bool rec = prof && prof->begin(st);
+        rc = launch_stack_assemble(frames_ring, masks_ring, cur, net->N, depth, head, rl, hw, net->in_ch_pad, x16, st);
+        if (rec) prof->end(st, PK_KERNEL_ASSEMBLE, 0, 4.0 * net->N * hw * (net->in_ch + net->in_ch_pad));
+        if (rc) return rc;
+        rc = run_forward(net, params, fold, nullptr, theta, ws, st, prof, true);
+        if (rc) return rc;
+        rec = prof && prof->begin(st);
+        rc = launch_mesh(theta, 1, net->N, grid_h, grid_w, 1.0f / do_crop_rate, nullptr, Hs, st);
+        if (rec) prof->end(st, PK_KERNEL_MESH, 0, 4.0 * net->N * (net->n_theta + grid_h * grid_w * 9));
+        if (rc) return rc;
+        rec = prof && prof->begin(st);
+        // the frame being warped is the (possibly refined) current frame: channel 2*n_lags of the stack
+        rc = launch_sample(Hs, cur, net->N, net->H, net->W, 1, grid_h, grid_w, out_img, black, x_map, y_map, st);
+        if (rec) prof->end(st, PK_KERNEL_WARP, 0, net->N * (20.0 * hw + 776.0));
+        if (rc) return rc;
+        // frame = img - black; with refine > 1 it replaces the current frame of the next pass (:293-295)
+        const bool last = (j == refine - 1);
+        rec = prof && prof->begin(st);
+        if (last)
+            rc = launch_ring_push(frames_ring, masks_ring, net->N, depth, head, out_img, black, hw, frame_fb, st);
+        else
+            rc = launch_ring_push(frame_fb, nullptr, net->N, 1, 0, out_img, black, hw, nullptr, st);
+        if (rec) prof->end(st, PK_KERNEL_PUSH, 0, 4.0 * net->N * hw * 4);
+        if (rc) return rc;
+        if (!last) cur = frame_fb;
+    }
+    return STABNET_OK;
 }
 
 }  // extern "C"

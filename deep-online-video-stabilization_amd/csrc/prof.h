@@ -1,0 +1,29 @@
+// Optional per-launch HIP-event instrumentation used by bench.py's roofline leg (never on by default).
+#pragma once
+#include <vector>
+#include "common.h"
+
+enum {
+    PK_KERNEL_PAD = 1, PK_KERNEL_POOL = 2, PK_KERNEL_GAP = 3, PK_KERNEL_FC = 4, PK_KERNEL_MESH = 5,
+    PK_KERNEL_WARP = 6, PK_KERNEL_ASSEMBLE = 7, PK_KERNEL_PUSH = 8, PK_KERNEL_SPLITK_REDUCE = 9,
+    PK_KERNEL_CONV_BASE = 100   // + tile*2 + (BK==32)
+};
+
+struct Prof {
+    std::vector<hipEvent_t> ev;     // 2 per record
+    std::vector<int> kind;
+    std::vector<double> flops, bytes;
+    std::vector<int> shape;         // 4 ints per record: M, N, K, split-K (0 when not a GEMM)
+    int cap = 0, n = 0;
+    bool begin(hipStream_t st) {
+        if (n >= cap) return false;
+        (void)hipEventRecord(ev[2 * n], st);
+        return true;
+    }
+    void end(hipStream_t st, int k, double f, double b, int sm = 0, int sn = 0, int sk = 0, int ss = 0) {
+        (void)hipEventRecord(ev[2 * n + 1], st);
+        kind[n] = k; flops[n] = f; bytes[n] = b;
+        shape[4 * n] = sm; shape[4 * n + 1] = sn; shape[4 * n + 2] = sk; shape[4 * n + 3] = ss;
+        ++n;
+    }
+};

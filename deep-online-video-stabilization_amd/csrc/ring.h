@@ -1,0 +1,11 @@
+// Launchers of the on-device history ring (ring.hip).
+#pragma once
+#include "common.h"
+
+struct RingLags { int lag[8]; int n; };
+
+int launch_ring_init(float* frames, float* masks, const float* first, int S, int depth, long hw, hipStream_t st);
+int launch_stack_assemble(const float* frames, const float* masks, const float* cur, int S, int depth, int head,
+                          const RingLags& lags, long hw, int Cp, float* out, hipStream_t st);
+int launch_ring_push(float* frames, float* masks, int S, int depth, int head, const float* img, const float* black,
+                     long hw, float* frame_out, hipStream_t st);

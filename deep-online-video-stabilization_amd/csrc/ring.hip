@@ -1,0 +1,89 @@
+// On-device history ring of the online loop (deploy_bundle.py:216-232,259-274,291-295,
+// 319-332).  The reference keeps Python lists of [1,H,W,1] NumPy frames and np.concatenate()s a 13-channel stack per
+// frame on the host; here the ring is a circular buffer in HBM, [S streams][depth][H*W] for stabilised frames and for
+// black masks, and the stack is assembled straight into the 16-channel padded NHWC tensor the stem conv reads.
+//   slot of lag i at time t: (head - i) mod depth, head = slot the NEXT push writes.
+#include "ring.h"
+
+__global__ __launch_bounds__(256) void ring_init_kernel(float* __restrict__ frames, float* __restrict__ masks,
+                                                        const float* __restrict__ first, int depth, long hw) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;       // pixel
+    const int s = blockIdx.y;
+    if (i >= hw) return;
+    const float v = first[(long)s * hw + i];
+    for (int d = 0; d < depth; ++d) {                            // 32 x first frame, zero masks (:216-224)
+        frames[((long)s * depth + d) * hw + i] = v;
+        masks[((long)s * depth + d) * hw + i] = 0.f;
+    }
+}
+
+// out[s][pix][c]: c in [0,n) masks at lags, [n,2n) frames at lags, 2n current frame, rest zero (channel padding).
+__global__ __launch_bounds__(256) void stack_assemble_kernel(const float* __restrict__ frames,
+                                                             const float* __restrict__ masks,
+                                                             const float* __restrict__ cur, int depth, int head,
+                                                             const RingLags lags, long hw, int Cp,
+                                                             float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.y;
+    if (i >= hw) return;
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = 0.f;
+    const int n = lags.n;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        if (l < n) {
+            int slot = (head - lags.lag[l]) % depth;
+            if (slot < 0) slot += depth;
+            const long off = ((long)s * depth + slot) * hw + i;
+            v[l] = masks[off];
+            v[n + l] = frames[off];
+        }
+    }
+    v[2 * n] = cur[(long)s * hw + i];
+    float* o = out + ((long)s * hw + i) * Cp;
+    if (Cp == 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(o + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else {
+        for (int c = 0; c < Cp; ++c) o[c] = v[c];
+    }
+}
+
+// frame = img + black * (-1) (:293); push frame and black into slot `head` (:322-323).
+__global__ __launch_bounds__(256) void ring_push_kernel(float* __restrict__ frames, float* __restrict__ masks, int depth,
+                                                        int head, const float* __restrict__ img,
+                                                        const float* __restrict__ black, long hw,
+                                                        float* __restrict__ frame_out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.y;
+    if (i >= hw) return;
+    const float b = black[(long)s * hw + i];
+    const float f = img[(long)s * hw + i] + b * -1.0f;
+    frames[((long)s * depth + head) * hw + i] = f;
+    if (masks != nullptr) masks[((long)s * depth + head) * hw + i] = b;
+    if (frame_out != nullptr) frame_out[(long)s * hw + i] = f;
+}
+
+int launch_ring_init(float* frames, float* masks, const float* first, int S, int depth, long hw, hipStream_t st) {
+    ring_init_kernel<<<dim3(cdiv(hw, 256), S), 256, 0, st>>>(frames, masks, first, depth, hw);
+    SN_LAUNCH_CHECK("ring_init_kernel");
+    return STABNET_OK;
+}
+
+int launch_stack_assemble(const float* frames, const float* masks, const float* cur, int S, int depth, int head,
+                          const RingLags& lags, long hw, int Cp, float* out, hipStream_t st) {
+    SN_REQUIRE(lags.n >= 1 && lags.n <= 7 && 2 * lags.n + 1 <= Cp && Cp <= 16, "stack_assemble: %d lags do not fit %d channels",
+               lags.n, Cp);
+    stack_assemble_kernel<<<dim3(cdiv(hw, 256), S), 256, 0, st>>>(frames, masks, cur, depth, head, lags, hw, Cp, out);
+    SN_LAUNCH_CHECK("stack_assemble_kernel");
+    return STABNET_OK;
+}
+
+int launch_ring_push(float* frames, float* masks, int S, int depth, int head, const float* img, const float* black,
+                     long hw, float* frame_out, hipStream_t st) {
+    ring_push_kernel<<<dim3(cdiv(hw, 256), S), 256, 0, st>>>(frames, masks, depth, head, img, black, hw, frame_out);
+    SN_LAUNCH_CHECK("ring_push_kernel");
+    return STABNET_OK;
+}

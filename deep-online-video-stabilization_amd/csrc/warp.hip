@@ -10,7 +10,7 @@
 //   get_4_pts   s_net_bundle_nobm.py:29-71        get_H/pinv  spatial_transformer3.py:144-175
 //   get_Hs      spatial_transformer3.py:179-198   _transform3 spatial_transformer3.py:218-301
 //   _interpolate spatial_transformer3.py:62-123   interpolate spatial_transformer.py:200-281
-#include "common.h"
+#include "warp.h"
 #include <climits>
 
 #define SN_MAX_CELLS 64
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ i
 }
 
 // ---------------------------------------------------------------------------------------------------------
-static int check_warp_args(int N, int H, int W, int C, int gh, int gw) {
+int check_warp_args(int N, int H, int W, int C, int gh, int gw) {
     SN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "warp: N,H,W,C must be positive (got %d,%d,%d,%d)", N, H, W, C);
     SN_REQUIRE(gh > 0 && gw > 0 && gh * gw <= SN_MAX_CELLS, "warp: grid %dx%d unsupported (max %d cells)", gh, gw,
                SN_MAX_CELLS);
@@ -272,7 +272,7 @@ static int check_warp_args(int N, int H, int W, int C, int gh, int gw) {
     return STABNET_OK;
 }
 
-static int launch_mesh(const float* in, int is_theta, int N, int gh, int gw, float lim, float* pts2, float* Hs,
+int launch_mesh(const float* in, int is_theta, int N, int gh, int gw, float lim, float* pts2, float* Hs,
                        hipStream_t st) {
     const long waves = (long)N * gh * gw;
     mesh_homography_kernel<<<cdiv(waves * 64, 256), 256, 0, st>>>(in, is_theta, N, gh, gw, lim, pts2, Hs);
@@ -280,7 +280,7 @@ static int launch_mesh(const float* in, int is_theta, int N, int gh, int gw, flo
     return STABNET_OK;
 }
 
-static int launch_sample(const float* Hs, const float* src, int N, int H, int W, int C, int gh, int gw, float* out,
+int launch_sample(const float* Hs, const float* src, int N, int H, int W, int C, int gh, int gw, float* out,
                          float* black, float* x_map, float* y_map, hipStream_t st) {
     dim3 grid(cdiv(W, 256), cdiv(H, 4), N);
     if ((W & 3) == 0)

@@ -1,0 +1,108 @@
+"""Host side of the online loop (deploy_bundle.py:183-342, the network + feedback part): an on-device history ring
+per stream and ONE C call per frame.  Video decode/encode and the colour remap stay with the caller."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._tensor import dev_f32, ptr, stream_ptr
+from .config import Config, v2_93
+from .regressor import Regressor
+
+
+class Profiler:
+    """Per-launch HIP-event records taken inside the library (bench.py roofline leg)."""
+
+    def __init__(self, max_records: int = 65536):
+        self._h = ctypes.c_void_p()
+        _lib.call("stabnet_prof_create", ctypes.byref(self._h), max_records)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def reset(self):
+        _lib.call("stabnet_prof_reset", self._h)
+
+    def records(self):
+        """[(kernel name, ms, flops, bytes)] -- synchronises the device first."""
+        torch.cuda.synchronize()
+        L = _lib.lib()
+        out = []
+        kind, ms, fl, by = ctypes.c_int(), ctypes.c_float(), ctypes.c_double(), ctypes.c_double()
+        for i in range(L.stabnet_prof_num_records(self._h)):
+            _lib.call("stabnet_prof_record", self._h, i, ctypes.byref(kind), ctypes.byref(ms), ctypes.byref(fl),
+                      ctypes.byref(by))
+            out.append((L.stabnet_prof_kind_name(kind.value).decode(), ms.value, fl.value, by.value))
+        return out
+
+    def records_with_shapes(self):
+        recs = self.records()
+        shp = (ctypes.c_int * 4)()
+        out = []
+        for i, r in enumerate(recs):
+            _lib.call("stabnet_prof_record_shape", self._h, i, shp)
+            out.append(r + (tuple(shp),))
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().stabnet_prof_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class StabNetStream:
+    """S independent video streams stabilised in lock-step on one GPU.
+
+    step(cur) takes the next unstable frames [S,H,W] (train-normalised grey, [-0.5,0.5]) and returns the tensors the
+    reference fetches at deploy_bundle.py:286 -- output_img, black_pix, Hs, x_map, y_map -- plus theta and the fed-back
+    frame (img - black).  before_ch is accepted and ignored exactly like the reference (deploy_bundle.py:15,41): the
+    ring depth is max(indices[1:])."""
+
+    def __init__(self, params, H: int, W: int, cfg: Config = v2_93, streams: int = 1, device="cuda:0", refine: int = 1,
+                 before_ch=None):
+        self.cfg, self.H, self.W, self.S, self.refine = cfg, H, W, streams, refine
+        self.reg = Regressor(params, streams, H, W, cfg, device)
+        dev = self.reg.device
+        self.lags = [i for i in cfg.indices[1:] if i > 0]
+        self.depth = max(self.lags)
+        self._lags_c = (ctypes.c_int * len(self.lags))(*self.lags)
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        self.frames_ring = f(streams, self.depth, H, W)
+        self.masks_ring = f(streams, self.depth, H, W)
+        self.theta = f(streams, cfg.n_theta)
+        self.out_img = f(streams, H, W, 1)
+        self.black = f(streams, H, W)
+        self.x_map = f(streams, H, W, 1)
+        self.y_map = f(streams, H, W, 1)
+        self.Hs = f(streams, cfg.grid_h, cfg.grid_w, 9)
+        self.frame_fb = f(streams, H, W)
+        self.head = 0
+        self.started = False
+
+    def start(self, first_frame: torch.Tensor):
+        first = dev_f32(first_frame, "first_frame").reshape(self.S, self.H, self.W)
+        _lib.call("stabnet_ring_init", ptr(self.frames_ring), ptr(self.masks_ring), ptr(first), self.S, self.depth,
+                  self.H, self.W, stream_ptr())
+        self.head = 0
+        self.started = True
+
+    def step(self, cur: torch.Tensor, prof: Profiler = None):
+        if not self.started:
+            raise _lib.StabnetError("StabNetStream.step before start(first_frame)")
+        cur = dev_f32(cur, "cur").reshape(self.S, self.H, self.W)
+        r = self.reg
+        _lib.call("stabnet_deploy_frame", r.plan.handle, ptr(r.params), ptr(r.fold), ptr(self.frames_ring),
+                  ptr(self.masks_ring), self.depth, self.head, self._lags_c, len(self.lags), ptr(cur), self.refine,
+                  self.cfg.grid_h, self.cfg.grid_w, self.cfg.do_crop_rate, ptr(self.theta), ptr(self.out_img),
+                  ptr(self.black), ptr(self.x_map), ptr(self.y_map), ptr(self.Hs), ptr(self.frame_fb),
+                  ptr(r.workspace), r.workspace.numel(), stream_ptr(), prof.handle if prof is not None else 0)
+        self.head = (self.head + 1) % self.depth
+        return {"output": self.out_img, "black_pix": self.black, "Hs": self.Hs, "x_map": self.x_map,
+                "y_map": self.y_map, "theta": self.theta, "frame": self.frame_fb}

@@ -110,7 +110,7 @@ class Regressor:
             tuple(x.shape), (p.N, p.H, p.W, self.cfg.in_ch))
         theta = out if out is not None else empty((p.N, self.cfg.n_theta), x)
         _lib.call("stabnet_backbone_fwd_infer", p.handle, ptr(self.params), ptr(self.fold), ptr(x), ptr(theta),
-                  ptr(self.workspace), self.workspace.numel(), stream_ptr())
+                  ptr(self.workspace), self.workspace.numel(), stream_ptr(), 0)
         return theta
 
     __call__ = forward

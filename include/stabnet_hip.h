@@ -102,7 +102,38 @@ int stabnet_net_fold_bn(const void* net, const float* params, float* fold, float
 
 /* x_tensor NHWC [N,H,W,in_ch] -> theta [N,n_theta]; BN in moving-average mode (s_net_bundle_nobm.py:302). */
 int stabnet_backbone_fwd_infer(const void* net, const float* params, const float* fold, const float* x_tensor,
-                               float* theta, void* workspace, size_t workspace_bytes, void* stream);
+                               float* theta, void* workspace, size_t workspace_bytes, void* stream, void* prof);
+
+/* ---- the online loop (deploy_bundle.py) ------------------------------------------------------------------ */
+
+/* History ring initialisation: `depth` copies of the first frame and zero masks per stream
+ * (deploy_bundle.py:216-224).  frames_ring, masks_ring: [S][depth][H*W]; first_frame [S][H*W]. */
+int stabnet_ring_init(float* frames_ring, float* masks_ring, const float* first_frame, int S, int depth, int H, int W,
+                      void* stream);
+
+/* One iteration of the hot loop for S = net.N independent streams (deploy_bundle.py:259-296,319-332), the work of
+ * one sess.run([output, black_pix, Hs, x_map, y_map], {x_tensor: in_x}) plus the NumPy stack assembly before it and
+ * the feedback after it:  13-channel stack from the ring at the dilated `lags` (HOST int array, e.g. 1,2,4,8,16,32;
+ * channel order masks, frames, current) -> regressor -> get_4_pts -> transformer -> frame = img - black ->
+ * frames_ring[head] = frame, masks_ring[head] = black.  refine > 1 repeats the network on the refined frame
+ * (:284-295).  The caller advances head = (head + 1) % depth after the call.
+ * Outputs: theta [S,n_theta]; out_img, black, x_map, y_map, frame_fb [S,H,W]; Hs [S,gh,gw,9]. */
+int stabnet_deploy_frame(const void* net, const float* params, const float* fold, float* frames_ring,
+                         float* masks_ring, int depth, int head, const int* lags, int n_lags, const float* cur_frame,
+                         int refine, int grid_h, int grid_w, float do_crop_rate, float* theta, float* out_img,
+                         float* black, float* x_map, float* y_map, float* Hs, float* frame_fb, void* workspace,
+                         size_t workspace_bytes, void* stream, void* prof);
+
+/* ---- optional per-launch timing (bench.py roofline leg) --------------------------------------------------
+ * A profiler handle owns HIP events (host objects).  Passing it as `prof` to a forward makes that call record an
+ * event pair around each kernel launch; read the records after synchronising the stream.  NULL = no instrumentation. */
+int stabnet_prof_create(void** prof, int max_records);
+void stabnet_prof_destroy(void* prof);
+int stabnet_prof_reset(void* prof);
+int stabnet_prof_num_records(const void* prof);
+int stabnet_prof_record(const void* prof, int idx, int* kind, float* ms, double* flops, double* bytes);
+int stabnet_prof_record_shape(const void* prof, int idx, int* shape4);
+const char* stabnet_prof_kind_name(int kind);
 
 #ifdef __cplusplus
 }
