@@ -15,187 +15,11 @@
 // issued one K-step ahead of the MFMAs (double-buffered LDS, one barrier per K-step).
 #include "conv.h"
 #include "prof.h"
+#include <climits>
+#include <cstdlib>
+#include <algorithm>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-template <int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
-    constexpr int PITCH = BK + 4;
-    constexpr int WAVES_N = BN / WN;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int F4_PER_ROW = BK / 4;
-    constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
-    constexpr int A_PASSES = BM / ROWS_PER_PASS;
-    constexpr int B_PASSES = BN / ROWS_PER_PASS;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
-    static_assert(A_PASSES >= 1 && B_PASSES >= 1, "tile too small for the loader");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const As0 = smem;
-    float* const Bs0 = smem + BM * PITCH;
-    constexpr int STAGE = (BM + BN) * PITCH;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-
-    const int cin_steps = p.Cin / BK;
-    const int total_steps = p.KH * p.KW * cin_steps;
-    const int ks_begin = blockIdx.z * p.steps_per_split;
-    const int ks_end = min(total_steps, ks_begin + p.steps_per_split);
-
-    // ---- loader mapping: thread -> (row within pass, float4 within the BK slice)
-    const int lrow = tid / F4_PER_ROW, lc4 = tid % F4_PER_ROW;
-    int a_base[A_PASSES], a_iy0[A_PASSES], a_ix0[A_PASSES];
-#pragma unroll
-    for (int ps = 0; ps < A_PASSES; ++ps) {
-        const int m = m0 + lrow + ps * ROWS_PER_PASS;
-        if (m < p.M) {
-            const int img = m / (p.Ho * p.Wo);
-            const int r = m - img * (p.Ho * p.Wo);
-            const int oy = r / p.Wo, ox = r - oy * p.Wo;
-            a_base[ps] = img * p.H;
-            a_iy0[ps] = oy * p.stride - p.pad;
-            a_ix0[ps] = ox * p.stride - p.pad;
-        } else {
-            a_base[ps] = -1;
-            a_iy0[ps] = 0;
-            a_ix0[ps] = 0;
-        }
-    }
-    const float* wrow[B_PASSES];
-#pragma unroll
-    for (int ps = 0; ps < B_PASSES; ++ps) {
-        const int n = n0 + lrow + ps * ROWS_PER_PASS;
-        wrow[ps] = (n < p.Cout) ? p.w + (size_t)n * p.K + lc4 * 4 : nullptr;
-    }
-
-    float4 ra[A_PASSES], rb[B_PASSES];
-    auto load_tiles = [&](int ks) {
-        const int tap = ks / cin_steps;
-        const int c0 = (ks - tap * cin_steps) * BK;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.in_scale != nullptr) {
-            sc = *reinterpret_cast<const float4*>(p.in_scale + c0 + lc4 * 4);
-            sh = *reinterpret_cast<const float4*>(p.in_shift + c0 + lc4 * 4);
-        }
-#pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps) {
-            int iy = a_iy0[ps] + kh, ix = a_ix0[ps] + kw;
-            bool ok = a_base[ps] >= 0 && iy >= 0 && ix >= 0;
-            if (p.up > 1) {
-                ok = ok && (iy % p.up == 0) && (ix % p.up == 0);
-                iy /= p.up;
-                ix /= p.up;
-            }
-            ok = ok && iy < p.H && ix < p.W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(p.x + ((size_t)(a_base[ps] + iy) * p.W + ix) * p.Cin + c0 + lc4 * 4);
-                if (p.in_scale != nullptr) {
-                    v.x = fmaxf(v.x * sc.x + sh.x, 0.f);
-                    v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
-                    v.z = fmaxf(v.z * sc.z + sh.z, 0.f);
-                    v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
-                }
-            }
-            ra[ps] = v;
-        }
-#pragma unroll
-        for (int ps = 0; ps < B_PASSES; ++ps) {
-            rb[ps] = (wrow[ps] != nullptr) ? *reinterpret_cast<const float4*>(wrow[ps] + (size_t)tap * p.Cin + c0)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_tiles = [&](int buf) {
-        float* As = As0 + buf * STAGE;
-        float* Bs = Bs0 + buf * STAGE;
-#pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps)
-            *reinterpret_cast<float4*>(As + (lrow + ps * ROWS_PER_PASS) * PITCH + lc4 * 4) = ra[ps];
-#pragma unroll
-        for (int ps = 0; ps < B_PASSES; ++ps)
-            *reinterpret_cast<float4*>(Bs + (lrow + ps * ROWS_PER_PASS) * PITCH + lc4 * 4) = rb[ps];
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    if (ks_begin < ks_end) {
-        load_tiles(ks_begin);
-        store_tiles(0);
-    }
-    __syncthreads();
-
-    const int frag_off = (lane & 31) * PITCH + (lane >> 5) * 4;
-    for (int ks = ks_begin; ks < ks_end; ++ks) {
-        const int buf = (ks - ks_begin) & 1;
-        if (ks + 1 < ks_end) load_tiles(ks + 1);          // global loads in flight under the MFMAs
-        const float* Ab = As0 + buf * STAGE + (wm * WM) * PITCH + frag_off;
-        const float* Bb = Bs0 + buf * STAGE + (wn * WN) * PITCH + frag_off;
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * PITCH + kk * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * PITCH + kk * 8);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (ks + 1 < ks_end) store_tiles(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool split = p.splitk > 1;
-    float* const outp = split ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : p.y;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + (lane & 31);
-        if (n >= p.Cout) continue;
-        const float bv = (!split && p.bias != nullptr) ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= p.M) continue;
-                float v = acc[i][j][r];
-                if (!split) {
-                    v += bv;
-                    if (p.residual != nullptr) {
-                        size_t ri;
-                        if (p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo) {
-                            ri = (size_t)m * p.Cout + n;
-                        } else {
-                            const int img = m / (p.Ho * p.Wo);
-                            const int rr = m - img * (p.Ho * p.Wo);
-                            const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
-                            ri = (((size_t)img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.Cout + n;
-                        }
-                        v += p.residual[ri];
-                    }
-                    if (p.relu_out) v = fmaxf(v, 0.f);
-                }
-                outp[(size_t)m * p.Cout + n] = v;
-            }
-        }
-    }
-}
+#include "conv_kernel.h"
 
 // Sums the split-K partial slabs in a fixed order and applies the epilogue.  One thread per 4 channels.
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs p) {
@@ -242,7 +66,20 @@ static void tile_dims(int t, int& bm, int& bn) {
     bn = (t == T128x128) ? 128 : 64;
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 static int pick_tile(const ConvArgs& a, int& splitk) {
+    static const int force_tile = env_int("STABNET_CONV_TILE", -1);      // tuning overrides (not used by default)
+    static const int force_split = env_int("STABNET_CONV_SPLITK", -1);
+    if (force_tile >= 0) {
+        const int bk0 = (a.Cin % 32 == 0) ? 32 : 16;
+        const int steps0 = a.KH * a.KW * (a.Cin / bk0);
+        splitk = force_split > 0 ? std::min(force_split, steps0) : 1;
+        return force_tile;
+    }
     const int bk = (a.Cin % 32 == 0) ? 32 : 16;
     const int total_steps = a.KH * a.KW * (a.Cin / bk);
     const int target = 512;                       // >= 2 blocks per CU over the 256 CUs
@@ -277,11 +114,11 @@ size_t conv_plan(ConvArgs& a) {
     return a.splitk > 1 ? (size_t)a.splitk * a.M * a.Cout * sizeof(float) : 0;
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
-static int launch_one(const ConvArgs& a, hipStream_t st) {
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
+template <int BM, int BN, int BK, int WM, int WN, int MODE, int NBUF>
+static int launch_one_nb(const ConvArgs& a, hipStream_t st) {
+    constexpr size_t lds = NBUF * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
     static bool configured = false;
-    auto kern = conv_igemm_f32_kernel<BM, BN, BK, WM, WN>;
+    auto kern = conv_igemm_f32_kernel<BM, BN, BK, WM, WN, MODE, NBUF>;
     if (!configured) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -297,6 +134,19 @@ static int launch_one(const ConvArgs& a, hipStream_t st) {
     kern<<<grid, 256, lds, st>>>(a);
     SN_LAUNCH_CHECK("conv_igemm_f32_kernel");
     return STABNET_OK;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int MODE>
+static int launch_one_t(const ConvArgs& a, hipStream_t st) {
+    static const int nbuf = env_int("STABNET_CONV_NBUF", 2);
+    return nbuf == 1 ? launch_one_nb<BM, BN, BK, WM, WN, MODE, 1>(a, st) : launch_one_nb<BM, BN, BK, WM, WN, MODE, 2>(a, st);
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+static int launch_one(const ConvArgs& a, hipStream_t st) {
+    if (a.up > 1) return launch_one_t<BM, BN, BK, WM, WN, 2>(a, st);
+    if (a.pad == 0) return launch_one_t<BM, BN, BK, WM, WN, 0>(a, st);
+    return launch_one_t<BM, BN, BK, WM, WN, 1>(a, st);
 }
 
 int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof) {
@@ -350,7 +200,9 @@ static int fill_args(ConvArgs& a, const float* x, const float* w, const float* b
     a.res_W = residual ? res_W : a.Wo;
     a.res_stride = residual ? res_stride : 1;
     a.relu_out = relu_out;
-    SN_REQUIRE((long)N * a.Ho * a.Wo < (1L << 31) && (long)N * H * W * Cin < (1L << 40), "conv2d: too large");
+    SN_REQUIRE((long)N * a.Ho * a.Wo * Cout < (1L << 30) && (long)N * (H + 2 * pad) * (W + 2 * pad) * Cin < (1L << 30) &&
+                   (long)Cout * KH * KW * Cin < (1L << 30), "conv2d: tensors must have < 2^30 elements");
+    SN_REQUIRE(KH * KW <= 64, "conv2d: filter larger than 64 taps");
     return STABNET_OK;
 }
 

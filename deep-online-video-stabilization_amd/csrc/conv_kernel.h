@@ -1,0 +1,254 @@
+// The implicit-GEMM convolution kernel template (shared by conv.hip and tools/conv_probe.hip).
+#pragma once
+#include "conv.h"
+#include <climits>
+
+#ifndef CONV_ABLATE
+#define CONV_ABLATE 0          // probe-only bit mask: 1 no global loads, 2 no LDS stores, 4 no epilogue stores, 8 no MFMA
+#endif
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// MODE 0: no padding and no dilation (1x1 convs, any stride): every tap of every row < M is in frame -> no masks.
+// MODE 1: zero padding: a per-row bit mask (one bit per filter tap, built once) says which taps are in frame.
+// MODE 2: dilated input (dgrad of a strided conv): validity and address are recomputed per tap (slow path).
+template <int BM, int BN, int BK, int WM, int WN, int MODE, int NBUF = 2>
+__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
+    constexpr int PITCH = BK + 4;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int F4_PER_ROW = BK / 4;
+    constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+    constexpr int A_PASSES = BM / ROWS_PER_PASS;
+    constexpr int B_PASSES = BN / ROWS_PER_PASS;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    static_assert(A_PASSES >= 1 && B_PASSES >= 1, "tile too small for the loader");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int STAGE = (BM + BN) * PITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    const int cin_steps = p.Cin / BK;
+    const int total_steps = p.KH * p.KW * cin_steps;
+    const int ks_begin = blockIdx.z * p.steps_per_split;
+    const int ks_end = min(total_steps, ks_begin + p.steps_per_split);
+
+    // ---- loader mapping: thread -> (row within pass, float4 within the BK slice).
+    // The K loop must stay (almost) free of vector ALU work: on gfx950 every VALU instruction costs ~3 cycles of
+    // f32-MFMA issue (measured, tools/mfma_probe.hip).  So each global address is  (wave-uniform base advanced with
+    // scalar adds) + (loop-invariant 32-bit per-lane byte offset): the `saddr + voffset` form of global_load.
+    // All offsets are 32-bit; the host checks every tensor has < 2^30 elements.
+    const int lrow = tid / F4_PER_ROW, lc4 = tid % F4_PER_ROW;
+    const int pad_off = (p.pad * p.W + p.pad) * p.Cin;           // shifts the per-lane offset to be non-negative
+    unsigned a_voff[A_PASSES];
+    unsigned long long a_mask[A_PASSES];                          // MODE 1: bit t set <=> tap t of this row is in frame
+    int a_iy0[A_PASSES], a_ix0[A_PASSES];                         // MODE 2 only
+    const unsigned safe_voff = (unsigned)(pad_off + lc4 * 4);    // + tap base = inside the first KH rows of image 0
+#pragma unroll
+    for (int ps = 0; ps < A_PASSES; ++ps) {
+        const int m = m0 + lrow + ps * ROWS_PER_PASS;
+        const int mc = min(m, p.M - 1);
+        const int img = mc / (p.Ho * p.Wo);
+        const int r = mc - img * (p.Ho * p.Wo);
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        a_iy0[ps] = iy0;
+        a_ix0[ps] = ix0;
+        a_mask[ps] = 0;
+        if (MODE == 2) {
+            a_voff[ps] = (unsigned)(img * p.H * p.W * p.Cin + lc4 * 4);
+            if (m >= p.M) a_iy0[ps] = -(1 << 28);
+        } else {
+            a_voff[ps] = (unsigned)(((img * p.H + iy0 + p.pad) * p.W + ix0 + p.pad) * p.Cin + lc4 * 4);
+            if (MODE == 1 && m < p.M) {
+                unsigned long long mk = 0;
+                for (int kh = 0; kh < p.KH; ++kh)
+                    for (int kw = 0; kw < p.KW; ++kw)
+                        if ((unsigned)(iy0 + kh) < (unsigned)p.H && (unsigned)(ix0 + kw) < (unsigned)p.W)
+                            mk |= 1ull << (kh * p.KW + kw);
+                a_mask[ps] = mk;
+            }
+        }
+    }
+    unsigned w_voff[B_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < B_PASSES; ++ps) {
+        const int n = n0 + lrow + ps * ROWS_PER_PASS;
+        w_voff[ps] = (unsigned)(min(n, p.Cout - 1) * p.K + lc4 * 4);     // rows >= Cout are never stored
+    }
+    const bool has_pro = p.in_scale != nullptr;
+    const float* const scp = has_pro ? p.in_scale : p.x;         // any valid address when there is no prologue
+    const float* const shp = has_pro ? p.in_shift : p.x;
+    const unsigned s_voff = has_pro ? (unsigned)(lc4 * 4) : 0u;
+
+    // K-iteration state (wave-uniform): tap (kh,kw) and channel offset c0 of the NEXT tile to load
+    int l_kh, l_kw, l_c0;
+    {
+        const int tap = ks_begin / cin_steps;
+        l_c0 = (ks_begin - tap * cin_steps) * BK;
+        l_kh = tap / p.KW;
+        l_kw = tap - l_kh * p.KW;
+    }
+
+    // Loads are unconditional (out-of-frame taps read a safe in-buffer address and are zeroed when the tile is written
+    // to LDS) and the BN+ReLU prologue runs at LDS-store time, AFTER the MFMAs of the current step: nothing between the
+    // global loads and the matrix work consumes the loaded registers, so the loads stay in flight under the MFMAs.
+    float4 ra[A_PASSES], rb[B_PASSES], sc, sh;
+    unsigned okmask = 0;
+    auto load_tiles = [&]() {
+        const int kh = l_kh, kw = l_kw, c0 = l_c0;
+        const int tap = kh * p.KW + kw;
+        okmask = 0;
+        if (MODE == 2) {
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps) {
+                int iy = a_iy0[ps] + kh, ix = a_ix0[ps] + kw;
+                bool ok = (iy >= 0) & (ix >= 0) & ((iy % p.up) == 0) & ((ix % p.up) == 0);
+                iy /= p.up;
+                ix /= p.up;
+                ok = ok & (iy < p.H) & (ix < p.W);
+                const unsigned off = a_voff[ps] + (unsigned)((iy * p.W + ix) * p.Cin + c0);
+                if (!(CONV_ABLATE & 1)) ra[ps] = *reinterpret_cast<const float4*>(p.x + (ok ? off : (unsigned)(lc4 * 4)));
+                okmask |= (ok ? 1u : 0u) << ps;
+            }
+        } else {
+            const float* xb = p.x + ((kh * p.W + kw) * p.Cin + c0 - pad_off);     // uniform; may point before p.x
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps) {
+                unsigned voff = a_voff[ps];
+                if (MODE == 1) {
+                    const bool ok = (a_mask[ps] >> tap) & 1ull;
+                    voff = ok ? voff : safe_voff;
+                    okmask |= (ok ? 1u : 0u) << ps;
+                }
+                if (!(CONV_ABLATE & 1)) ra[ps] = *reinterpret_cast<const float4*>(xb + voff);
+            }
+        }
+        const float* wb = p.w + (tap * p.Cin + c0);                                 // uniform
+#pragma unroll
+        for (int ps = 0; ps < B_PASSES; ++ps)
+            if (!(CONV_ABLATE & 1)) rb[ps] = *reinterpret_cast<const float4*>(wb + w_voff[ps]);
+        sc = *reinterpret_cast<const float4*>(scp + (has_pro ? c0 : 0) + s_voff);
+        sh = *reinterpret_cast<const float4*>(shp + (has_pro ? c0 : 0) + s_voff);
+        l_c0 += BK;
+        if (l_c0 == p.Cin) {
+            l_c0 = 0;
+            if (++l_kw == p.KW) { l_kw = 0; ++l_kh; }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + BM * PITCH;
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps) {
+            float4 v = ra[ps];
+            if (has_pro) {
+                v.x = fmaxf(__builtin_fmaf(v.x, sc.x, sh.x), 0.f);
+                v.y = fmaxf(__builtin_fmaf(v.y, sc.y, sh.y), 0.f);
+                v.z = fmaxf(__builtin_fmaf(v.z, sc.z, sh.z), 0.f);
+                v.w = fmaxf(__builtin_fmaf(v.w, sc.w, sh.w), 0.f);
+            }
+            if (MODE != 0 && !((okmask >> ps) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(CONV_ABLATE & 2)) *reinterpret_cast<float4*>(As + (lrow + ps * ROWS_PER_PASS) * PITCH + lc4 * 4) = v;
+            else asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+        }
+#pragma unroll
+        for (int ps = 0; ps < B_PASSES; ++ps) {
+            const float4 v = rb[ps];
+            if (!(CONV_ABLATE & 2)) *reinterpret_cast<float4*>(Bs + (lrow + ps * ROWS_PER_PASS) * PITCH + lc4 * 4) = v;
+            else asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (ks_begin < ks_end) {
+        load_tiles();
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    const int frag_off = (lane & 31) * PITCH + (lane >> 5) * 4;
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+        const int buf = (NBUF == 2) ? ((ks - ks_begin) & 1) : 0;
+        if (ks + 1 < ks_end) load_tiles();                // global loads in flight under the MFMAs
+        const float* Ab = smem + buf * STAGE + (wm * WM) * PITCH + frag_off;
+        const float* Bb = smem + buf * STAGE + (BM + wn * WN) * PITCH + frag_off;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * PITCH + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * PITCH + kk * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (NBUF == 1) __syncthreads();                   // single LDS stage: everyone is done reading it
+        if (ks + 1 < ks_end) store_tiles(NBUF == 2 ? (buf ^ 1) : 0);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool split = p.splitk > 1;
+    float* const outp = split ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : p.y;
+    const bool has_res = !split && p.residual != nullptr;
+    const bool res_plain = p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mrow0 = m0 + wm * WM + i * 32 + 4 * (lane >> 5);
+        int roff[16];                                     // residual element offset of each accumulator row
+        if (has_res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = min(mrow0 + (r & 3) + 8 * (r >> 2), p.M - 1);
+                if (res_plain) {
+                    roff[r] = m * p.Cout;
+                } else {
+                    const int img = m / (p.Ho * p.Wo);
+                    const int rr = m - img * (p.Ho * p.Wo);
+                    const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
+                    roff[r] = ((img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.Cout;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + (lane & 31);
+            const bool ncol = n < p.Cout;
+            const int nc = min(n, p.Cout - 1);
+            const float bv = (!split && p.bias != nullptr) ? p.bias[nc] : 0.f;
+            float rv[16];
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = p.residual[(unsigned)(roff[r] + nc)];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] + bv;
+                if (has_res) v += rv[r];
+                if (!split && p.relu_out) v = fmaxf(v, 0.f);
+                if (!(CONV_ABLATE & 4)) { if (ncol && m < p.M) outp[(size_t)m * p.Cout + n] = v; }
+                else if (v == 123.456f) outp[0] = v;
+            }
+        }
+    }
+}
+

@@ -65,7 +65,20 @@ def test_full_frame_matches_oracle(cuda):
     flips = r["black_pix"].cpu().numpy() != ref["black_pix"]
     edge = (np.abs(np.abs(ref["x_map"][..., 0]) - 1) < 1e-4) | (np.abs(np.abs(ref["y_map"][..., 0]) - 1) < 1e-4)
     assert not (flips & ~edge).any()
-    assert np.abs(r["output"].cpu().numpy() - ref["output"]).max() < 2e-3     # image gradient ~ O(10/px) * map error
+    # warped pixels: bilinear sampling is Lipschitz in the sample position with constant <= 2*G per pixel of
+    # displacement (G = largest neighbour difference of the source frame), so the map tolerance bounds the pixel error
+    src = x[0, :, :, 2 * cfg.before_ch]
+    G = max(np.abs(np.diff(src, axis=0)).max(), np.abs(np.diff(src, axis=1)).max())
+    dpx = np.abs(xm - ref["x_map"]) * W / 2 + np.abs(ym - ref["y_map"]) * H / 2
+    bound = 2 * G * dpx[..., 0] + 1e-5
+    # ... except where the sample sits on the frame border: there the reference's clipped-corner weights make the
+    # sampler discontinuous (in-frame value vs ~0), so a 1e-4 map difference may legitimately flip the pixel
+    xp = (ref["x_map"][..., 0] + 1) * W / 2
+    yp = (ref["y_map"][..., 0] + 1) * H / 2
+    tol = 0.05
+    border = (np.abs(xp) < tol) | (np.abs(xp - (W - 1)) < tol) | (np.abs(yp) < tol) | (np.abs(yp - (H - 1)) < tol)
+    err = np.abs(r["output"].cpu().numpy() - ref["output"])[..., 0]
+    assert (err <= bound)[~border].all(), "max excess %g" % float((err - bound)[~border].max())
     # given the oracle's theta, everything downstream is bit-exact
     r2 = warp.warp_from_theta(cur, torch.from_numpy(ref["theta"]).to(cuda), cfg)
     assert np.array_equal(r2["output"].cpu().numpy(), ref["output"])
