@@ -1,0 +1,75 @@
+"""Host wrappers of the training-side C-ABI entry points (backward of warp/sampler, loss kernels)."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._tensor import dev_f32, empty, ptr, stream_ptr
+from .config import Config, v2_93
+
+
+def transformer_bwd(pts2, Hs, U, x_map, y_map, d_out=None, d_xmap=None, d_ymap=None, cfg: Config = v2_93):
+    U = dev_f32(U, "U")
+    N, H, W, C = U.shape
+    d_pts2 = empty((N, cfg.grid_h + 1, cfg.grid_w + 1, 2), U)
+    ws = empty((N * cfg.grid_h * cfg.grid_w * 8,), U, dtype=torch.float64)
+    _lib.call("stabnet_transformer_bwd", ptr(dev_f32(pts2)), ptr(dev_f32(Hs)), ptr(U), ptr(dev_f32(x_map)),
+              ptr(dev_f32(y_map)), ptr(d_out), ptr(d_xmap), ptr(d_ymap), N, H, W, C, cfg.grid_h, cfg.grid_w, ptr(d_pts2),
+              ptr(ws), stream_ptr())
+    return d_pts2
+
+
+def interp_bwd(x, y, d_out):
+    d_out = dev_f32(d_out, "d_out")
+    N, H, W, C = d_out.shape
+    d_im = empty((N, H, W, C), d_out)
+    _lib.call("stabnet_interp_bwd", ptr(dev_f32(x)), ptr(dev_f32(y)), ptr(d_out), N, H, W, C, ptr(d_im), stream_ptr())
+    return d_im
+
+
+def masked_mse_sums(a, b, black, m2=None):
+    a = dev_f32(a)
+    N = a.shape[0]
+    hw = a.numel() // N
+    sums = empty((N, 2), a)
+    _lib.call("stabnet_masked_mse_sums", ptr(a), ptr(dev_f32(b)), ptr(dev_f32(black)), ptr(m2), N, hw, ptr(sums),
+              stream_ptr())
+    return sums
+
+
+def masked_mse_grad(a, b, black, m2, sums, coef, ga=None, accumulate_a=False, want_gb=False):
+    a = dev_f32(a)
+    N = a.shape[0]
+    hw = a.numel() // N
+    if ga is None:
+        ga = torch.empty_like(a)
+        accumulate_a = False
+    gb = torch.empty_like(a) if want_gb else None
+    _lib.call("stabnet_masked_mse_grad", ptr(a), ptr(dev_f32(b)), ptr(dev_f32(black)), ptr(m2), ptr(sums), float(coef),
+              N, hw, ptr(ga), int(accumulate_a), ptr(gb), stream_ptr())
+    return ga, gb
+
+
+def feature_loss(matches, mask, x_map, y_map, gcoef=0.0, want_grad=False, want_warped=False):
+    matches = dev_f32(matches)
+    N, Mx, _ = matches.shape
+    x_map = dev_f32(x_map)
+    H, W = x_map.shape[1], x_map.shape[2]
+    value = empty((N,), matches)
+    dxm = empty((N, H, W), matches) if want_grad else None
+    dym = empty((N, H, W), matches) if want_grad else None
+    warped = empty((N, Mx, 2), matches) if want_warped else None
+    _lib.call("stabnet_feature_loss", ptr(matches), ptr(dev_f32(mask)), ptr(x_map), ptr(dev_f32(y_map)), N, H, W, Mx,
+              float(gcoef), ptr(value), ptr(dxm), ptr(dym), ptr(warped), stream_ptr())
+    return value, dxm, dym, warped
+
+
+def mesh_losses(theta, d_pts2_warp, cfg: Config, w_id, w_dist, w_cons, use_black, w_black):
+    theta = dev_f32(theta)
+    N = theta.shape[0]
+    losses = empty((4,), theta)
+    d_theta = torch.empty_like(theta)
+    _lib.call("stabnet_mesh_losses", ptr(theta), ptr(d_pts2_warp), N, cfg.grid_h, cfg.grid_w, cfg.do_crop_rate,
+              cfg.id_mul, float(w_id), float(w_dist), float(w_cons), float(use_black), float(w_black), ptr(losses),
+              ptr(d_theta), stream_ptr())
+    return losses, d_theta

@@ -135,6 +135,42 @@ int stabnet_prof_record(const void* prof, int idx, int* kind, float* ms, double*
 int stabnet_prof_record_shape(const void* prof, int idx, int* shape4);
 const char* stabnet_prof_kind_name(int kind);
 
+/* ---- training: backward of the warp / sampler and the loss kernels ---------------------------------------
+ * These replace what TF autodiff generates for `opt.minimize(total_loss)` (train_bundle_nobm.py:160) over the ops
+ * above.  floor / casts / comparisons carry no gradient (corners, black_pix, z sign, warp_pts indices are constants). */
+
+/* d transformer / d pts2 (pre-clip vertex gradient) [N,gh+1,gw+1,2] from d_out [N,H,W,C], d_xmap, d_ymap [N,H,W]
+ * (each may be NULL).  x_map, y_map, Hs: the forward's outputs.  workspace: N*gh*gw*8 doubles (8-B aligned). */
+int stabnet_transformer_bwd(const float* pts2, const float* Hs, const float* U, const float* x_map, const float* y_map,
+                            const float* d_out, const float* d_xmap, const float* d_ymap, int N, int H, int W, int C,
+                            int grid_h, int grid_w, float* d_pts2, void* workspace, void* stream);
+
+/* d interpolate(im, x, y) / d im  (train_bundle_nobm.py:117-118): scatter-add of the four taps; d_im is zeroed here. */
+int stabnet_interp_bwd(const float* x, const float* y, const float* d_out, int N, int H, int W, int C, float* d_im,
+                       void* stream);
+
+/* masked MSE of img_loss (s_net_bundle_nobm.py:347-352, m2 = NULL) and temp_loss (train_bundle_nobm.py:110-125,
+ * m2 = interp(1 - black2)): sums [N,2] = {sum((a-b)m)^2, sum m}, m = (1 - black) * m2;
+ * loss = sum_n sums[n][0] / (sums[n][1] + 1e-8) / batch_size.  _grad: ga (+)= coef * dloss_unnormalised/da, gb = -that. */
+int stabnet_masked_mse_sums(const float* a, const float* b, const float* black, const float* m2, int N, long hw,
+                            float* sums, void* stream);
+int stabnet_masked_mse_grad(const float* a, const float* b, const float* black, const float* m2, const float* sums,
+                            float coef, int N, long hw, float* ga, int accumulate_a, float* gb, void* stream);
+
+/* feature loss (s_net_bundle_nobm.py:215-230,335-343): value [N] = masked mean L1 between the maps gathered at the
+ * rounded stable point and the unstable point; gradient (coefficient gcoef) scattered into d_xmap, d_ymap (zeroed here;
+ * both NULL = forward only); warped [N,max_matches,2] optional (ret['stable_warpped']). */
+int stabnet_feature_loss(const float* matches, const float* mask, const float* x_map, const float* y_map, int N, int H,
+                         int W, int max_matches, float gcoef, float* value, float* d_xmap, float* d_ymap,
+                         float* warped, void* stream);
+
+/* losses4 = {id2_loss (= mean|theta| * id_mul, :263), black_pos mean (:139-146,312-317), distortion (:148-181),
+ * consistency (:183-210)}; d_theta [N,n_theta] = clip-mask (:58) * (d_pts2_warp + w_dist d dist + w_cons d cons +
+ * w_black d black) + w_id * d id2_loss. */
+int stabnet_mesh_losses(const float* theta, const float* d_pts2_warp, int N, int grid_h, int grid_w, float do_crop_rate,
+                        float id_mul, float w_id, float w_dist, float w_cons, float use_black, float w_black,
+                        float* losses4, float* d_theta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,17 +67,22 @@ def get_Hs(pts2, cfg):
     return torch.stack(out, dim=1).reshape(N, gh, gw, 9)
 
 
-def _sample(im, x, y):
-    """spatial_transformer3.py:62-123; im [N,H,W,C]; x,y [N,H,W] -> [N,H,W,C]."""
+def _sample(im, x, y, corners=None):
+    """spatial_transformer3.py:62-123; im [N,H,W,C]; x,y [N,H,W] -> [N,H,W,C].
+    corners = (x0, y0, x1, y1) clipped int arrays: the (non-differentiable) floor decisions taken in float32 by the
+    forward pass; given, they replace this function's float64 floor so that both sides differentiate the same graph."""
     N, H, W, C = im.shape
     xp = (x + 1.0) * W / 2.0
     yp = (y + 1.0) * H / 2.0
     with torch.no_grad():
-        x0 = torch.floor(xp).clamp(-2 ** 31, 2 ** 31 - 1).long()
-        y0 = torch.floor(yp).clamp(-2 ** 31, 2 ** 31 - 1).long()
-        x1, y1 = x0 + 1, y0 + 1
-        x0, x1 = x0.clamp(0, W - 1), x1.clamp(0, W - 1)
-        y0, y1 = y0.clamp(0, H - 1), y1.clamp(0, H - 1)
+        if corners is not None:
+            x0, y0, x1, y1 = [torch.as_tensor(np.asarray(c).reshape(N, H, W).astype(np.int64)) for c in corners]
+        else:
+            x0 = torch.floor(xp).clamp(-2 ** 31, 2 ** 31 - 1).long()
+            y0 = torch.floor(yp).clamp(-2 ** 31, 2 ** 31 - 1).long()
+            x1, y1 = x0 + 1, y0 + 1
+            x0, x1 = x0.clamp(0, W - 1), x1.clamp(0, W - 1)
+            y0, y1 = y0.clamp(0, H - 1), y1.clamp(0, H - 1)
         base = (torch.arange(N) * H * W)[:, None, None]
         ia, ib, ic, idd = base + y0 * W + x0, base + y1 * W + x0, base + y0 * W + x1, base + y1 * W + x1
     flat = im.reshape(-1, C)
@@ -90,7 +95,7 @@ def _sample(im, x, y):
     return (wa * Ia + wb * Ib + wc * Ic + wd * Id).reshape(N, H, W, C)
 
 
-def transformer(U, pts2, cfg):
+def transformer(U, pts2, cfg, corners=None):
     """spatial_transformer3.py:218-301 -> (out [N,H,W,C], black [N,H,W], maps [N,H,W,2])."""
     N, H, W, C = U.shape
     gh, gw = cfg.grid_h, cfg.grid_w
@@ -118,14 +123,14 @@ def transformer(U, pts2, cfg):
     x_map = torch.cat(xrows, dim=1)
     y_map = torch.cat(yrows, dim=1)
     black = ((x_map < -1) | (x_map > 1) | (y_map < -1) | (y_map > 1)).to(DT).detach()
-    out = _sample(U, x_map, y_map)
+    out = _sample(U, x_map, y_map, corners)
     return out, black, torch.stack([x_map, y_map], dim=3), Hs
 
 
-def interpolate(im, x, y):
+def interpolate(im, x, y, corners=None):
     """spatial_transformer.py:200-281."""
     N, H, W, C = im.shape
-    return _sample(im, x.reshape(N, H, W), y.reshape(N, H, W))
+    return _sample(im, x.reshape(N, H, W), y.reshape(N, H, W), corners)
 
 
 # ---- losses ------------------------------------------------------------------------------------------------
