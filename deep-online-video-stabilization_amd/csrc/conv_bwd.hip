@@ -1,0 +1,244 @@
+// Convolution backward on the gfx950 matrix cores (exact float32 MFMA), the autodiff of slim conv2d that
+// `opt.minimize` (train_bundle_nobm.py:160) runs for every conv of resnet_v2_50:
+//
+//   wgrad : dW[n][(kh,kw,c)] += sum_m dY[m][n] * act(x)[pix(m,kh,kw)][c]          (this file, its own kernel)
+//   dgrad : dX = conv(dY dilated by the forward stride, W flipped and transposed)   (the forward kernel of conv.hip
+//                                                                                    on weights re-packed here)
+//
+// wgrad tiling: the reduction runs over output pixels m, which is the slow index of both operands in memory
+// (dY[m][n], x[pix][c]), so tiles are staged in LDS as [pixel][64 channels] exactly as loaded and the MFMA operands
+// are read with ds_read_b32 (lane&31 -> consecutive channels: conflict-free).  Block = 64 output channels x 64
+// k-columns, 4 waves (32x32 each), 32 pixels per step, double-buffered; the M range is split over blockIdx.z and the
+// partial sums are accumulated with float atomics (dW is small; both towers of the siamese step add into it).
+#include "conv.h"
+#include "prof.h"
+#include "train_layers.h"
+#include <algorithm>
+
+typedef float f32x16w __attribute__((ext_vector_type(16)));
+
+struct WgradArgs {
+    const float* x;          // forward input NHWC [N,H,W,Cin]
+    const float* dy;         // output gradient NHWC [N,Ho,Wo,Cout]
+    float* dw;               // OHWI [Cout][KH][KW][Cin], accumulated into
+    const float* in_scale;   // forward prologue (folded BN + ReLU) or null
+    const float* in_shift;
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+    int M, K, rows_per_split;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs p) {
+    constexpr int BR = 32, BT = 64;
+    __shared__ __attribute__((aligned(16))) float sY[2][BR][BT];
+    __shared__ __attribute__((aligned(16))) float sA[2][BR][BT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * BT, k0 = blockIdx.y * BT;
+    const int m_begin = blockIdx.z * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    if (m_begin >= m_end) return;
+
+    // loader mapping: thread -> (pixel row r = tid/16 and r+16, float4 column q = tid%16)
+    const int lq = tid & 15, lr = tid >> 4;
+    const int kcol = k0 + lq * 4;                          // this thread's k-columns: fixed tap and channels
+    const bool k_ok = kcol < p.K;
+    const int tap = k_ok ? kcol / p.Cin : 0;
+    const int c_t = k_ok ? kcol - tap * p.Cin : 0;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int ncol = n0 + lq * 4;
+    const bool n_ok = ncol < p.Cout;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool has_pro = p.in_scale != nullptr;
+    if (has_pro && k_ok) {
+        sc = *reinterpret_cast<const float4*>(p.in_scale + c_t);
+        sh = *reinterpret_cast<const float4*>(p.in_shift + c_t);
+    }
+    // pixel coordinates of the two rows this thread loads, advanced incrementally by BR per step
+    int img[2], oy[2], ox[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = m_begin + lr + 16 * t;
+        img[t] = m / (p.Ho * p.Wo);
+        const int r = m - img[t] * (p.Ho * p.Wo);
+        oy[t] = r / p.Wo;
+        ox[t] = r - oy[t] * p.Wo;
+    }
+    float4 ry[2], ra[2];
+    unsigned ok = 0;
+    int m_cur = m_begin;
+    auto load_tiles = [&]() {
+        ok = 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int m = m_cur + lr + 16 * t;
+            const bool row_ok = m < m_end;
+            const int iy = oy[t] * p.stride - p.pad + kh, ix = ox[t] * p.stride - p.pad + kw;
+            const bool a_ok = row_ok && k_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned yoff = (row_ok && n_ok) ? (unsigned)(m * p.Cout + ncol) : 0u;
+            const unsigned aoff = a_ok ? (unsigned)(((img[t] * p.H + iy) * p.W + ix) * p.Cin + c_t) : 0u;
+            ry[t] = *reinterpret_cast<const float4*>(p.dy + yoff);
+            ra[t] = *reinterpret_cast<const float4*>(p.x + aoff);
+            ok |= ((row_ok && n_ok) ? 1u : 0u) << (2 * t);
+            ok |= (a_ok ? 2u : 0u) << (2 * t);
+            // advance this row by BR pixels
+            ox[t] += BR;
+            while (ox[t] >= p.Wo) {
+                ox[t] -= p.Wo;
+                if (++oy[t] == p.Ho) { oy[t] = 0; ++img[t]; }
+            }
+        }
+        m_cur += BR;
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float4 y = ry[t], a = ra[t];
+            if (has_pro) {
+                a.x = fmaxf(__builtin_fmaf(a.x, sc.x, sh.x), 0.f);
+                a.y = fmaxf(__builtin_fmaf(a.y, sc.y, sh.y), 0.f);
+                a.z = fmaxf(__builtin_fmaf(a.z, sc.z, sh.z), 0.f);
+                a.w = fmaxf(__builtin_fmaf(a.w, sc.w, sh.w), 0.f);
+            }
+            if (!((ok >> (2 * t)) & 1u)) y = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!((ok >> (2 * t)) & 2u)) a = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&sY[buf][lr + 16 * t][lq * 4]) = y;
+            *reinterpret_cast<float4*>(&sA[buf][lr + 16 * t][lq * 4]) = a;
+        }
+    };
+
+    f32x16w acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;   // wave's 32x32 sub-tile: rows = out channels, cols = k
+    const int li = lane & 31, lh = lane >> 5;
+
+    load_tiles();
+    store_tiles(0);
+    __syncthreads();
+    const int steps = (m_end - m_begin + BR - 1) / BR;
+    for (int s = 0; s < steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < steps) load_tiles();
+#pragma unroll
+        for (int kk = 0; kk < BR / 2; ++kk) {
+            const float a = sY[buf][2 * kk + lh][wn + li];
+            const float b = sA[buf][2 * kk + lh][wk + li];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (s + 1 < steps) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    // C/D map: col = lane&31 (k), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (out channel)
+    const int k = k0 + wk + li;
+    if (k < p.K) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (n < p.Cout) atomicAdd(&p.dw[(size_t)n * p.K + k], acc[r]);
+        }
+    }
+}
+
+// Wt[ci][kh][kw][co] = W[co][KH-1-kh][KW-1-kw][ci]  : the weights of the dgrad convolution (OHWI in, OHWI out)
+__global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                                 int Cout, int KH, int KW, int Cin) {
+    const long total = (long)Cout * KH * KW * Cin;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    const int co = (int)(q % Cout);
+    long r = q / Cout;
+    const int kw = (int)(r % KW); r /= KW;
+    const int kh = (int)(r % KH);
+    const int ci = (int)(r / KH);
+    wt[q] = w[(((size_t)co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * Cin + ci];
+}
+
+int wgrad_launch(const float* x, const float* dy, float* dw, const float* in_scale, const float* in_shift, int N, int H,
+                 int W, int Cin, int Cout, int KH, int KW, int stride, int pad, hipStream_t st, Prof* prof) {
+    WgradArgs a{};
+    a.x = x; a.dy = dy; a.dw = dw; a.in_scale = in_scale; a.in_shift = in_shift;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.Ho = (H + 2 * pad - KH) / stride + 1;
+    a.Wo = (W + 2 * pad - KW) / stride + 1;
+    a.M = N * a.Ho * a.Wo;
+    a.K = KH * KW * Cin;
+    SN_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "wgrad: channel counts must be multiples of 4");
+    SN_REQUIRE((long)a.M * Cout < (1L << 31) && (long)N * H * W * Cin < (1L << 31), "wgrad: tensors must have < 2^31 elements");
+    const int tiles = cdiv(Cout, 64) * cdiv(a.K, 64);
+    int splits = std::max(1, std::min(cdiv(1024, tiles), cdiv(a.M, 256)));      // >= 256 pixels (8 steps) per block
+    splits = std::min(splits, 65535);
+    a.rows_per_split = cdiv(cdiv(a.M, splits), 32) * 32;
+    splits = cdiv(a.M, a.rows_per_split);
+    const bool rec = prof != nullptr && prof->begin(st);
+    conv_wgrad_f32_kernel<<<dim3(cdiv(Cout, 64), cdiv(a.K, 64), splits), 256, 0, st>>>(a);
+    if (rec) prof->end(st, PK_KERNEL_WGRAD, 2.0 * a.M * (double)a.K * Cout,
+                       4.0 * ((double)a.M * Cout + (double)N * H * W * Cin + (double)a.K * Cout * splits), Cout, a.K, a.M, splits);
+    SN_LAUNCH_CHECK("conv_wgrad_f32_kernel");
+    return STABNET_OK;
+}
+
+int pack_dgrad_weights(const float* w, float* wt, int Cout, int KH, int KW, int Cin, hipStream_t st) {
+    const long total = (long)Cout * KH * KW * Cin;
+    pack_dgrad_weights_kernel<<<cdiv(total, 256), 256, 0, st>>>(w, wt, Cout, KH, KW, Cin);
+    SN_LAUNCH_CHECK("pack_dgrad_weights_kernel");
+    return STABNET_OK;
+}
+
+// dX [N,H,W,Cin] = dgrad of a forward conv (x [N,H,W,Cin] -> y [N,Ho,Wo,Cout], KHxKW, stride, pad) from dY and the
+// re-packed weights wt [Cin][KH][KW][Cout].  residual (optional, same shape as dX) is added (gradient accumulation).
+int dgrad_launch(const float* dy, const float* wt, float* dx, const float* residual, int N, int H, int W, int Cin,
+                 int Cout, int KH, int KW, int stride, int pad, float* splitk_ws, size_t splitk_bytes, hipStream_t st,
+                 Prof* prof) {
+    ConvArgs a{};
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    a.x = dy; a.w = wt; a.y = dx; a.residual = residual;
+    a.N = N; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Cout = Cin; a.KH = KH; a.KW = KW;
+    a.stride = 1; a.pad = KH - 1 - pad; a.up = stride;
+    a.Ho = H; a.Wo = W; a.res_H = H; a.res_W = W; a.res_stride = 1;
+    SN_REQUIRE(a.pad >= 0 && Cout % 16 == 0, "dgrad: unsupported geometry (pad %d, Cout %d)", a.pad, Cout);
+    const size_t need = conv_plan(a);
+    if (need > splitk_bytes) {
+        stabnet_set_error("dgrad: split-K workspace %zu B < %zu B", splitk_bytes, need);
+        return STABNET_ERR_WORKSPACE;
+    }
+    a.partial = splitk_ws;
+    return conv_launch(a, st, prof);
+}
+
+extern "C" {
+
+/* d conv2d / d weights, accumulated into dw (OHWI [Cout][KH][KW][Cin], NOT zeroed here).  x: the forward input,
+ * (in_scale, in_shift): the forward's folded-BN + ReLU prologue (or NULL), dy [N,Ho,Wo,Cout]. */
+int stabnet_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* in_scale, const float* in_shift,
+                         int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+    SN_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
+    SN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
+    return wgrad_launch(x, dy, dw, in_scale, in_shift, N, H, W, Cin, Cout, KH, KW, stride, pad, (hipStream_t)stream, nullptr);
+}
+
+/* d conv2d / d input: dx [N,H,W,Cin] (+ residual if given) from dy [N,Ho,Wo,Cout] and the forward weights
+ * w_ohwi [Cout][KH][KW][Cin].  workspace: Cout*KH*KW*Cin floats for the re-packed weights, followed by
+ * stabnet_conv2d_dgrad_workspace_bytes() - that.  Cout % 16 == 0. */
+size_t stabnet_conv2d_dgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    ConvArgs a{};
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    a.N = N; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Cout = Cin; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = KH - 1 - pad;
+    a.up = stride; a.Ho = H; a.Wo = W;
+    return (size_t)Cout * KH * KW * Cin * sizeof(float) + conv_plan(a) + 256;
+}
+int stabnet_conv2d_dgrad(const float* dy, const float* w_ohwi, float* dx, const float* residual, int N, int H, int W,
+                         int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    SN_REQUIRE(dy && w_ohwi && dx && workspace, "conv2d_dgrad: null pointer");
+    const size_t wbytes = (size_t)Cout * KH * KW * Cin * sizeof(float);
+    SN_REQUIRE(workspace_bytes >= stabnet_conv2d_dgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad),
+               "conv2d_dgrad: workspace too small");
+    float* wt = static_cast<float*>(workspace);
+    int rc = pack_dgrad_weights(w_ohwi, wt, Cout, KH, KW, Cin, (hipStream_t)stream);
+    if (rc) return rc;
+    const size_t off = (wbytes + 255) & ~(size_t)255;
+    return dgrad_launch(dy, wt, dx, residual, N, H, W, Cin, Cout, KH, KW, stride, pad,
+                        reinterpret_cast<float*>(static_cast<char*>(workspace) + off), workspace_bytes - off,
+                        (hipStream_t)stream, nullptr);
+}
+
+}  // extern "C"

@@ -395,6 +395,7 @@ const char* stabnet_prof_kind_name(int kind) {
         case PK_KERNEL_ASSEMBLE: return "stack_assemble_kernel";
         case PK_KERNEL_PUSH: return "ring_push_kernel";
         case PK_KERNEL_SPLITK_REDUCE: return "conv_splitk_reduce_kernel";
+        case PK_KERNEL_WGRAD: return "conv_wgrad_f32_kernel";
         case PK_KERNEL_CONV_BASE + 0: return "conv_igemm_f32_kernel<128,128,16,64,64>";
         case PK_KERNEL_CONV_BASE + 1: return "conv_igemm_f32_kernel<128,128,32,64,64>";
         case PK_KERNEL_CONV_BASE + 2: return "conv_igemm_f32_kernel<128,64,16,64,32>";

@@ -1,0 +1,30 @@
+// Launchers of the training-mode layers (train_layers.hip) and of the convolution backward (conv_bwd.hip).
+#pragma once
+#include "common.h"
+
+struct Prof;
+
+size_t col_reduce_workspace_floats(long M, int C);
+int launch_bn_stats(const float* x, long M, int C, const float* gamma, const float* beta, float eps, float decay,
+                    float* scale, float* shift, float* save_mean, float* save_invstd, float* mov_mean, float* mov_var,
+                    float* partial, hipStream_t st);
+int launch_bn_relu_bwd(const float* x, const float* g, const float* scale, const float* shift, const float* mean,
+                       const float* invstd, const float* gamma, long M, int C, const float* addend, int add_stride, int H,
+                       int W, float* d_gamma, float* d_beta, float* d_x, float* partial, float* coef, hipStream_t st);
+int launch_bias_grad(const float* g, long M, int C, float* d_bias, float* partial, hipStream_t st);
+int launch_max_pool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo, int k,
+                        int stride, int pt, int pl, hipStream_t st);
+int launch_gap_bwd(const float* dg, int N, int HW, int C, float* da, hipStream_t st);
+int launch_fc_bwd(const float* x, const float* w, const float* y, const float* dy, int M, int K, int Nout, int relu,
+                  float* dW, float* db, float* dx, hipStream_t st);
+int launch_weight_decay(const float* params, float* grads, const long* seg_off, const long* seg_len, const float* seg_coef,
+                        int nseg, float gscale, float* loss_out, hipStream_t st);
+int launch_adam(float* w, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
+                float gscale, hipStream_t st);
+
+int wgrad_launch(const float* x, const float* dy, float* dw, const float* in_scale, const float* in_shift, int N, int H,
+                 int W, int Cin, int Cout, int KH, int KW, int stride, int pad, hipStream_t st, Prof* prof);
+int pack_dgrad_weights(const float* w, float* wt, int Cout, int KH, int KW, int Cin, hipStream_t st);
+int dgrad_launch(const float* dy, const float* wt, float* dx, const float* residual, int N, int H, int W, int Cin,
+                 int Cout, int KH, int KW, int stride, int pad, float* splitk_ws, size_t splitk_bytes, hipStream_t st,
+                 Prof* prof);

@@ -1,0 +1,411 @@
+// Training-mode layers of the regressor other than the convolutions (gfx950): batch-statistics BN forward and
+// backward, bias gradients, max-pool / global-pool / FC backward, weight decay, Adam.  All HBM-bound.
+//   slim batch_norm(is_training=True): tf.nn.moments (biased variance) + moving-average update
+//   (decay 0.997, variable -= (variable - value) * (1 - decay)); the UPDATE_OPS run with the step (s_net_bundle_nobm.py:355-356).
+#include "train_layers.h"
+#include <algorithm>
+
+// ---------------------------------------------------------------------------------------------------------
+// Column reductions over an [M][C] tensor, two stages (deterministic order):
+//   MODE 0: (sum x, sum x^2)                           BN batch statistics
+//   MODE 1: (sum dz, sum dz*xhat), dz = g*(a>0)        BN+ReLU backward;  a = x*scale+shift, xhat = (x-mean)*invstd
+//   MODE 2: (sum g, -)                                 bias gradient
+// block = 16 channel-quads x 16 row lanes; grid = (C/64, chunks); partial [chunks][2][C].
+template <int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         long M, int C, long rows_per_chunk, float* __restrict__ partial) {
+    __shared__ float4 s0[16][16], s1[16][16];
+    const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + q * 4;
+    const long r0 = (long)blockIdx.y * rows_per_chunk;
+    const long r1 = min(M, r0 + rows_per_chunk);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    if (c < C) {
+        float4 sc = a0, sh = a0, mu = a0, is = a0;
+        if (MODE == 1) {
+            sc = *reinterpret_cast<const float4*>(scale + c); sh = *reinterpret_cast<const float4*>(shift + c);
+            mu = *reinterpret_cast<const float4*>(mean + c); is = *reinterpret_cast<const float4*>(invstd + c);
+        }
+        for (long r = r0 + rl; r < r1; r += 16) {
+            if (MODE == 0) {
+                const float4 v = *reinterpret_cast<const float4*>(x + r * C + c);
+                a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+                a1.x += v.x * v.x; a1.y += v.y * v.y; a1.z += v.z * v.z; a1.w += v.w * v.w;
+            } else if (MODE == 1) {
+                const float4 v = *reinterpret_cast<const float4*>(x + r * C + c);
+                float4 d = *reinterpret_cast<const float4*>(g + r * C + c);
+                d.x = (v.x * sc.x + sh.x > 0.f) ? d.x : 0.f; d.y = (v.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
+                d.z = (v.z * sc.z + sh.z > 0.f) ? d.z : 0.f; d.w = (v.w * sc.w + sh.w > 0.f) ? d.w : 0.f;
+                a0.x += d.x; a0.y += d.y; a0.z += d.z; a0.w += d.w;
+                a1.x += d.x * (v.x - mu.x) * is.x; a1.y += d.y * (v.y - mu.y) * is.y;
+                a1.z += d.z * (v.z - mu.z) * is.z; a1.w += d.w * (v.w - mu.w) * is.w;
+            } else {
+                const float4 d = *reinterpret_cast<const float4*>(g + r * C + c);
+                a0.x += d.x; a0.y += d.y; a0.z += d.z; a0.w += d.w;
+            }
+        }
+    }
+    s0[rl][q] = a0;
+    s1[rl][q] = a1;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float4 t0 = s0[0][q], t1 = s1[0][q];
+        for (int i = 1; i < 16; ++i) {
+            const float4 u = s0[i][q], w = s1[i][q];
+            t0.x += u.x; t0.y += u.y; t0.z += u.z; t0.w += u.w;
+            t1.x += w.x; t1.y += w.y; t1.z += w.z; t1.w += w.w;
+        }
+        float* p = partial + (size_t)blockIdx.y * 2 * C;
+        *reinterpret_cast<float4*>(p + c) = t0;
+        *reinterpret_cast<float4*>(p + C + c) = t1;
+    }
+}
+
+// BN statistics finalize: batch mean / biased variance (float64 combine) -> folded (scale, shift), saved (mean, invstd),
+// moving averages.
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int chunks, long M, int C,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float eps, float decay, float* __restrict__ scale,
+                                                                float* __restrict__ shift, float* __restrict__ save_mean,
+                                                                float* __restrict__ save_invstd, float* __restrict__ mov_mean,
+                                                                float* __restrict__ mov_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        s += (double)partial[(size_t)k * 2 * C + c];
+        ss += (double)partial[(size_t)k * 2 * C + C + c];
+    }
+    const double mean = s / (double)M;
+    const double var = fmax(ss / (double)M - mean * mean, 0.0);
+    const float meanf = (float)mean, varf = (float)var;
+    const float is = 1.0f / sqrtf(varf + eps);
+    const float inv = is * gamma[c];
+    scale[c] = inv;
+    shift[c] = beta[c] - meanf * inv;
+    save_mean[c] = meanf;
+    save_invstd[c] = is;
+    if (mov_mean != nullptr) {
+        mov_mean[c] -= (mov_mean[c] - meanf) * (1.0f - decay);
+        mov_var[c] -= (mov_var[c] - varf) * (1.0f - decay);
+    }
+}
+
+// BN backward finalize: d_gamma += sum dz*xhat, d_beta += sum dz; coefficients for the apply pass:
+// coef[0][c] = gamma*invstd, coef[1][c] = mean(dz), coef[2][c] = mean(dz*xhat).
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, long M, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                              float* __restrict__ d_gamma, float* __restrict__ d_beta,
+                                                              float* __restrict__ coef) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, sx = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        s += (double)partial[(size_t)k * 2 * C + c];
+        sx += (double)partial[(size_t)k * 2 * C + C + c];
+    }
+    d_beta[c] += (float)s;
+    d_gamma[c] += (float)sx;
+    coef[c] = gamma[c] * invstd[c];
+    coef[C + c] = (float)(s / (double)M);
+    coef[2 * C + c] = (float)(sx / (double)M);
+}
+
+__global__ __launch_bounds__(256) void bias_grad_finalize_kernel(const float* __restrict__ partial, int chunks, int C,
+                                                                 float* __restrict__ d_bias) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < chunks; ++k) s += (double)partial[(size_t)k * 2 * C + c];
+    d_bias[c] += (float)s;
+}
+
+// d_x = k1 * (dz - c1 - xhat * c2)  (+ addend[n, y/s, x/s, c] where y%s == 0 and x%s == 0: the identity-shortcut branch).
+// g may alias d_x (in-place).  One thread per float4.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* g,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ coef, const float* __restrict__ addend,
+                                                           int add_stride, int H, int W, long M, int C, float* d_x) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = C / 4;
+    if (i >= M * c4n) return;
+    const long r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + r * C + c);
+    float4 d = *reinterpret_cast<const float4*>(g + r * C + c);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+    const float4 k1 = *reinterpret_cast<const float4*>(coef + c), c1 = *reinterpret_cast<const float4*>(coef + C + c);
+    const float4 c2 = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+    d.x = (v.x * sc.x + sh.x > 0.f) ? d.x : 0.f; d.y = (v.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
+    d.z = (v.z * sc.z + sh.z > 0.f) ? d.z : 0.f; d.w = (v.w * sc.w + sh.w > 0.f) ? d.w : 0.f;
+    float4 o;
+    o.x = k1.x * (d.x - c1.x - (v.x - mu.x) * is.x * c2.x);
+    o.y = k1.y * (d.y - c1.y - (v.y - mu.y) * is.y * c2.y);
+    o.z = k1.z * (d.z - c1.z - (v.z - mu.z) * is.z * c2.z);
+    o.w = k1.w * (d.w - c1.w - (v.w - mu.w) * is.w * c2.w);
+    if (addend != nullptr) {
+        bool take = true;
+        long ar = r;
+        if (add_stride > 1) {
+            const int xw = (int)(r % W);
+            const long t = r / W;
+            const int yh = (int)(t % H);
+            const long n = t / H;
+            take = (xw % add_stride == 0) && (yh % add_stride == 0);
+            const int Hs = (H + add_stride - 1) / add_stride, Ws = (W + add_stride - 1) / add_stride;
+            ar = (n * Hs + yh / add_stride) * Ws + xw / add_stride;
+        }
+        if (take) {
+            const float4 a = *reinterpret_cast<const float4*>(addend + ar * C + c);
+            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+    }
+    *reinterpret_cast<float4*>(d_x + r * C + c) = o;
+}
+
+// max_pool2d backward, gather form (deterministic): an input pixel receives the gradient of every window whose first
+// maximum (scan order dy, dx) it is.
+__global__ __launch_bounds__(256) void max_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int N, int H, int W, int C, int Ho,
+                                                           int Wo, int k, int stride, int pt, int pl) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)N * H * W * C;
+    if (q >= total) return;
+    const int c = (int)(q % C);
+    long r = q / C;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    const int n = (int)(r / H);
+    const float v = x[q];
+    float acc = 0.f;
+    const int oy_lo = max(0, (iy + pt - k + stride) / stride), oy_hi = min(Ho - 1, (iy + pt) / stride);
+    const int ox_lo = max(0, (ix + pl - k + stride) / stride), ox_hi = min(Wo - 1, (ix + pl) / stride);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy)
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            // is (iy, ix) the first maximum of window (oy, ox)?
+            bool first_max = true;
+            for (int dyy = 0; dyy < k && first_max; ++dyy) {
+                const int yy = oy * stride - pt + dyy;
+                if (yy < 0 || yy >= H) continue;
+                for (int dxx = 0; dxx < k; ++dxx) {
+                    const int xx = ox * stride - pl + dxx;
+                    if (xx < 0 || xx >= W) continue;
+                    const float u = x[(((long)n * H + yy) * W + xx) * C + c];
+                    const bool before = (yy < iy) || (yy == iy && xx < ix);
+                    if (u > v || (u == v && before)) { first_max = false; break; }
+                }
+            }
+            if (first_max) acc += dy[(((long)n * Ho + oy) * Wo + ox) * C + c];
+        }
+    dx[q] = acc;
+}
+
+// d a[n,hw,c] = d g[n,c] / HW   (reduce_mean backward; the BN+ReLU before it is handled by the BN backward kernels)
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dg, int HW, int C, long total,
+                                                      float* __restrict__ da) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    const int c = (int)(q % C);
+    const long n = q / ((long)HW * C);
+    da[q] = dg[n * C + c] / (float)HW;
+}
+
+// FC backward.  dyr = dy * (y > 0) when relu.  dW[n][k] += sum_m dyr[m][n] x[m][k];  db[n] += sum_m dyr[m][n].
+__global__ __launch_bounds__(256) void fc_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                       const float* __restrict__ dy, int M, int K, int Nout, int relu,
+                                                       float* __restrict__ dW, float* __restrict__ db) {
+    const int n = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    float acc = 0.f, bacc = 0.f;
+    for (int m = 0; m < M; ++m) {
+        float d = dy[(size_t)m * Nout + n];
+        if (relu && !(y[(size_t)m * Nout + n] > 0.f)) d = 0.f;
+        bacc += d;
+        if (k < K) acc += d * x[(size_t)m * K + k];
+    }
+    if (k < K) dW[(size_t)n * K + k] += acc;
+    if (k == 0) db[n] += bacc;
+}
+
+// dx[m][k] = sum_n dyr[m][n] W[n][k]; n range split over blockIdx.y, float atomics into zeroed dx.
+__global__ __launch_bounds__(256) void fc_bwd_x_kernel(const float* __restrict__ w, const float* __restrict__ y,
+                                                       const float* __restrict__ dy, int M, int K, int Nout, int relu,
+                                                       int n_per_block, float* __restrict__ dx) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const int nb = blockIdx.y * n_per_block, ne = min(Nout, nb + n_per_block);
+    for (int m0 = 0; m0 < M; m0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int n = nb; n < ne; ++n) {
+            const float wv = w[(size_t)n * K + k];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + i;
+                if (m < M) {
+                    float d = dy[(size_t)m * Nout + n];
+                    if (relu && !(y[(size_t)m * Nout + n] > 0.f)) d = 0.f;
+                    acc[i] += d * wv;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (m0 + i < M) atomicAdd(&dx[(size_t)(m0 + i) * K + k], acc[i]);
+    }
+}
+
+// Weight decay: loss += coef_seg * 0.5 * sum w^2 (value into *loss_out via atomics), grad += gscale * coef_seg * w.
+// seg table (device): [offset, length] as int64 pairs + coef as float, one block column per segment.
+__global__ __launch_bounds__(256) void weight_decay_kernel(const float* __restrict__ params, float* __restrict__ grads,
+                                                           const long* __restrict__ seg_off, const long* __restrict__ seg_len,
+                                                           const float* __restrict__ seg_coef, float gscale,
+                                                           float* __restrict__ loss_out) {
+    const int sgi = blockIdx.y;
+    const long off = seg_off[sgi], len = seg_len[sgi];
+    const float coef = seg_coef[sgi];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < len; i += (long)gridDim.x * 256) {
+        const float w = params[off + i];
+        s += w * w;
+        if (grads != nullptr) grads[off + i] += gscale * coef * w;
+    }
+    if (loss_out != nullptr) {
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        __shared__ float red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(loss_out, 0.5f * coef * ((red[0] + red[1]) + (red[2] + red[3])));
+    }
+}
+
+// tf.train.AdamOptimizer step (TF 1.x): lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);
+// m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  w -= lr_t * m / (sqrt(v) + eps).   g is multiplied by gscale first.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr_t, float b1, float b2,
+                                                   float eps, float gscale) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n) {
+        float4 wv = *reinterpret_cast<float4*>(w + i), mv = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+        float4 gv = *reinterpret_cast<const float4*>(g + i);
+        gv.x *= gscale; gv.y *= gscale; gv.z *= gscale; gv.w *= gscale;
+        mv.x = b1 * mv.x + (1.f - b1) * gv.x; mv.y = b1 * mv.y + (1.f - b1) * gv.y;
+        mv.z = b1 * mv.z + (1.f - b1) * gv.z; mv.w = b1 * mv.w + (1.f - b1) * gv.w;
+        vv.x = b2 * vv.x + (1.f - b2) * gv.x * gv.x; vv.y = b2 * vv.y + (1.f - b2) * gv.y * gv.y;
+        vv.z = b2 * vv.z + (1.f - b2) * gv.z * gv.z; vv.w = b2 * vv.w + (1.f - b2) * gv.w * gv.w;
+        wv.x -= lr_t * mv.x / (sqrtf(vv.x) + eps); wv.y -= lr_t * mv.y / (sqrtf(vv.y) + eps);
+        wv.z -= lr_t * mv.z / (sqrtf(vv.z) + eps); wv.w -= lr_t * mv.w / (sqrtf(vv.w) + eps);
+        *reinterpret_cast<float4*>(w + i) = wv; *reinterpret_cast<float4*>(m + i) = mv; *reinterpret_cast<float4*>(v + i) = vv;
+    } else {
+        for (long j = i; j < n; ++j) {
+            const float gg = g[j] * gscale;
+            m[j] = b1 * m[j] + (1.f - b1) * gg;
+            v[j] = b2 * v[j] + (1.f - b2) * gg * gg;
+            w[j] -= lr_t * m[j] / (sqrtf(v[j]) + eps);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static int reduce_chunks(long M, long& rows_per_chunk) {
+    int chunks = (int)std::min<long>(std::max<long>(M / 512, 1), 256);
+    rows_per_chunk = (M + chunks - 1) / chunks;
+    return (int)((M + rows_per_chunk - 1) / rows_per_chunk);
+}
+
+size_t col_reduce_workspace_floats(long M, int C) {
+    long rpc;
+    const int chunks = reduce_chunks(M, rpc);
+    return (size_t)chunks * 2 * C;
+}
+
+int launch_bn_stats(const float* x, long M, int C, const float* gamma, const float* beta, float eps, float decay,
+                    float* scale, float* shift, float* save_mean, float* save_invstd, float* mov_mean, float* mov_var,
+                    float* partial, hipStream_t st) {
+    SN_REQUIRE(C % 4 == 0, "bn_stats: C %% 4 != 0");
+    long rpc;
+    const int chunks = reduce_chunks(M, rpc);
+    col_reduce_kernel<0><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, rpc, partial);
+    SN_LAUNCH_CHECK("col_reduce_kernel<0>");
+    bn_stats_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(partial, chunks, M, C, gamma, beta, eps, decay, scale, shift,
+                                                           save_mean, save_invstd, mov_mean, mov_var);
+    SN_LAUNCH_CHECK("bn_stats_finalize_kernel");
+    return STABNET_OK;
+}
+
+int launch_bn_relu_bwd(const float* x, const float* g, const float* scale, const float* shift, const float* mean,
+                       const float* invstd, const float* gamma, long M, int C, const float* addend, int add_stride, int H,
+                       int W, float* d_gamma, float* d_beta, float* d_x, float* partial, float* coef, hipStream_t st) {
+    SN_REQUIRE(C % 4 == 0, "bn_bwd: C %% 4 != 0");
+    long rpc;
+    const int chunks = reduce_chunks(M, rpc);
+    col_reduce_kernel<1><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(x, g, scale, shift, mean, invstd, M, C, rpc, partial);
+    SN_LAUNCH_CHECK("col_reduce_kernel<1>");
+    bn_bwd_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(partial, chunks, M, C, gamma, invstd, d_gamma, d_beta, coef);
+    SN_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+    bn_bwd_apply_kernel<<<cdiv(M * (C / 4), 256), 256, 0, st>>>(x, g, scale, shift, mean, invstd, coef, addend, add_stride, H,
+                                                                W, M, C, d_x);
+    SN_LAUNCH_CHECK("bn_bwd_apply_kernel");
+    return STABNET_OK;
+}
+
+int launch_bias_grad(const float* g, long M, int C, float* d_bias, float* partial, hipStream_t st) {
+    SN_REQUIRE(C % 4 == 0, "bias_grad: C %% 4 != 0");
+    long rpc;
+    const int chunks = reduce_chunks(M, rpc);
+    col_reduce_kernel<2><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(nullptr, g, nullptr, nullptr, nullptr, nullptr, M, C, rpc, partial);
+    SN_LAUNCH_CHECK("col_reduce_kernel<2>");
+    bias_grad_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(partial, chunks, C, d_bias);
+    SN_LAUNCH_CHECK("bias_grad_finalize_kernel");
+    return STABNET_OK;
+}
+
+int launch_max_pool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo, int k,
+                        int stride, int pt, int pl, hipStream_t st) {
+    max_pool_bwd_kernel<<<cdiv((long)N * H * W * C, 256), 256, 0, st>>>(x, dy, dx, N, H, W, C, Ho, Wo, k, stride, pt, pl);
+    SN_LAUNCH_CHECK("max_pool_bwd_kernel");
+    return STABNET_OK;
+}
+
+int launch_gap_bwd(const float* dg, int N, int HW, int C, float* da, hipStream_t st) {
+    const long total = (long)N * HW * C;
+    gap_bwd_kernel<<<cdiv(total, 256), 256, 0, st>>>(dg, HW, C, total, da);
+    SN_LAUNCH_CHECK("gap_bwd_kernel");
+    return STABNET_OK;
+}
+
+int launch_fc_bwd(const float* x, const float* w, const float* y, const float* dy, int M, int K, int Nout, int relu,
+                  float* dW, float* db, float* dx, hipStream_t st) {
+    fc_bwd_w_kernel<<<dim3(cdiv(K, 256), Nout), 256, 0, st>>>(x, y, dy, M, K, Nout, relu, dW, db);
+    SN_LAUNCH_CHECK("fc_bwd_w_kernel");
+    if (dx != nullptr) {
+        if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)M * K, st) != hipSuccess) {
+            stabnet_set_error("fc_bwd: memset failed");
+            return STABNET_ERR_LAUNCH;
+        }
+        const int npb = 32;
+        fc_bwd_x_kernel<<<dim3(cdiv(K, 256), cdiv(Nout, npb)), 256, 0, st>>>(w, y, dy, M, K, Nout, relu, npb, dx);
+        SN_LAUNCH_CHECK("fc_bwd_x_kernel");
+    }
+    return STABNET_OK;
+}
+
+int launch_weight_decay(const float* params, float* grads, const long* seg_off, const long* seg_len, const float* seg_coef,
+                        int nseg, float gscale, float* loss_out, hipStream_t st) {
+    weight_decay_kernel<<<dim3(64, nseg), 256, 0, st>>>(params, grads, seg_off, seg_len, seg_coef, gscale, loss_out);
+    SN_LAUNCH_CHECK("weight_decay_kernel");
+    return STABNET_OK;
+}
+
+int launch_adam(float* w, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
+                float gscale, hipStream_t st) {
+    adam_kernel<<<cdiv((n + 3) / 4, 256), 256, 0, st>>>(w, g, m, v, n, lr_t, b1, b2, eps, gscale);
+    SN_LAUNCH_CHECK("adam_kernel");
+    return STABNET_OK;
+}

@@ -40,3 +40,31 @@ def conv2d(x, w_ohwi, bias=None, in_scale=None, in_shift=None, residual=None, re
               res_stride, ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, int(relu_out), ptr(ws), ws_bytes,
               stream_ptr())
     return y
+
+
+def conv2d_wgrad(x, dy, w_shape, in_scale=None, in_shift=None, stride=1, pad=0, dw=None):
+    """dW (OHWI) += d conv / d W; returns dw (zero-initialised when not given)."""
+    x = dev_f32(x, "x")
+    dy = dev_f32(dy, "dy")
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, Cw = w_shape
+    assert Cw == Cin
+    if dw is None:
+        dw = torch.zeros(w_shape, dtype=torch.float32, device=x.device)
+    _lib.call("stabnet_conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(in_scale), ptr(in_shift), N, H, W, Cin, Cout, KH, KW,
+              stride, pad, stream_ptr())
+    return dw
+
+
+def conv2d_dgrad(dy, w_ohwi, x_shape, stride=1, pad=0, residual=None):
+    dy = dev_f32(dy, "dy")
+    w = dev_f32(w_ohwi, "w")
+    N, H, W, Cin = x_shape
+    Cout, KH, KW, _ = w.shape
+    dx = torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+    L = _lib.lib()
+    nbytes = L.stabnet_conv2d_dgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    _lib.call("stabnet_conv2d_dgrad", ptr(dy), ptr(w), ptr(dx), ptr(residual), N, H, W, Cin, Cout, KH, KW, stride, pad,
+              ptr(ws), nbytes, stream_ptr())
+    return dx

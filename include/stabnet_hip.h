@@ -171,6 +171,20 @@ int stabnet_mesh_losses(const float* theta, const float* d_pts2_warp, int N, int
                         float id_mul, float w_id, float w_dist, float w_cons, float use_black, float w_black,
                         float* losses4, float* d_theta, void* stream);
 
+/* ---- training: convolution backward (autodiff of slim conv2d) --------------------------------------------- */
+
+/* dW (OHWI, ACCUMULATED into, not zeroed) += d conv2d / d weights.  x: forward input; (in_scale,in_shift): the forward's
+ * folded-BN + ReLU prologue (both or NULL); dy [N,Ho,Wo,Cout].  Exact float32 MFMA, float atomics across pixel splits. */
+int stabnet_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* in_scale, const float* in_shift,
+                         int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
+
+/* dx [N,H,W,Cin] = d conv2d / d input (+ residual if given, may alias dx) from dy [N,Ho,Wo,Cout] and the forward
+ * weights (OHWI).  Cout % 16 == 0.  workspace: stabnet_conv2d_dgrad_workspace_bytes() (re-packed weights + split-K). */
+size_t stabnet_conv2d_dgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int stabnet_conv2d_dgrad(const float* dy, const float* w_ohwi, float* dx, const float* residual, int N, int H, int W,
+                         int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,48 @@
+"""GPU: convolution backward (wgrad MFMA kernel, dgrad through the forward kernel) vs torch CPU float64 autograd."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fnn
+
+pytestmark = pytest.mark.gpu
+
+# N,H,W,Cin,Cout,k,stride,pad,prologue
+CASES = [
+    (2, 18, 24, 64, 64, 1, 1, 0, True),
+    (2, 18, 24, 64, 64, 3, 1, 1, True),
+    (1, 19, 23, 64, 128, 3, 2, 1, True),      # strided conv2, odd sizes -> dilated dgrad
+    (2, 9, 16, 256, 64, 1, 1, 0, True),
+    (1, 20, 28, 16, 64, 7, 2, 3, False),      # stem (wgrad only is used by the net; dgrad checked too)
+    (3, 12, 12, 128, 512, 1, 1, 0, False),
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad,pro", CASES)
+def test_conv_backward(cuda, N, H, W, Cin, Cout, k, stride, pad, pro):
+    from stabnet_amd import ops
+    rng = np.random.default_rng(Cin + Cout + k)
+    x = rng.standard_normal((N, H, W, Cin))
+    w = rng.standard_normal((Cout, k, k, Cin)) * np.sqrt(2.0 / (k * k * Cin))
+    sc = rng.uniform(0.5, 1.5, Cin) if pro else None
+    sh = rng.standard_normal(Cin) * 0.3 if pro else None
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    a = torch.relu(xt * torch.tensor(sc) + torch.tensor(sh)) if pro else xt
+    a.retain_grad()
+    y = Fnn.conv2d(a.permute(0, 3, 1, 2), wt.permute(0, 3, 1, 2), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    g = rng.standard_normal(tuple(y.shape))
+    (y * torch.tensor(g)).sum().backward()
+    f = lambda v: None if v is None else torch.tensor(np.ascontiguousarray(v), dtype=torch.float32, device=cuda)
+    dw = ops.conv2d_wgrad(f(x), f(g), (Cout, k, k, Cin), f(sc), f(sh), stride, pad)
+    want = wt.grad.numpy()
+    assert np.abs(dw.cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max() * np.sqrt(N * H * W / 64 + 1)
+    if Cout % 16 == 0:
+        dx = ops.conv2d_dgrad(f(g), f(w), (N, H, W, Cin), stride, pad)
+        want = a.grad.numpy()                                   # gradient wrt the activated input of the conv
+        assert np.abs(dx.cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max()
+        res = rng.standard_normal((N, H, W, Cin))
+        dx2 = ops.conv2d_dgrad(f(g), f(w), (N, H, W, Cin), stride, pad, residual=f(res))
+        assert np.abs(dx2.cpu().numpy() - (want + res)).max() <= 2e-5 * np.abs(want + res).max()
+    # accumulation semantics of wgrad (second tower adds)
+    dw2 = ops.conv2d_wgrad(f(x), f(g), (Cout, k, k, Cin), f(sc), f(sh), stride, pad, dw=dw.clone())
+    assert torch.allclose(dw2, 2 * dw, rtol=1e-4, atol=1e-5 * float(dw.abs().max()))
