@@ -18,6 +18,7 @@
 #include "layers.h"
 #include "prof.h"
 #include "ring.h"
+#include "train_layers.h"
 #include "warp.h"
 
 enum { PK_CONV_W = 0, PK_BIAS = 1, PK_GAMMA = 2, PK_BETA = 3, PK_MEAN = 4, PK_VAR = 5, PK_FC_W = 6, PK_FC_B = 7 };
@@ -78,8 +79,25 @@ struct Arena {                                    // first-fit free list over th
     }
 };
 
+struct TensorRef { long off; size_t size; int N, H, W, C; };
+
+struct UnitInfo {                                 // one bottleneck unit, for the explicit backward schedule
+    TensorRef x, sc, r1, r2, out;
+    bool proj;
+    int stride, cin, dbn, depth;
+    long bn_pre, bn1, bn2;                        // channel offsets inside the BN sections
+    long w_sc, b_sc, w1, w2, w3, b3;
+};
+struct BnInfo { long chan_off; int C; long tensor_off; long M; int H, W; };
+
 struct Net {
     int N, H, W, in_ch, in_ch_pad, n_theta, keep_all;
+    std::vector<UnitInfo> units;
+    std::vector<BnInfo> bns;
+    TensorRef t_xin{}, t_c1{}, t_pool{}, t_last{}, t_gap{}, t_fc[3]{};
+    long w_stem = 0, b_stem = 0, bn_post = 0, fc_w[4] = {0, 0, 0, 0}, fc_b[4] = {0, 0, 0, 0};
+    int pool_pt = 0, pool_pl = 0, fc_dims[5] = {0, 0, 0, 0, 0};
+    size_t max_net = 0, max_r = 0, max_w = 0, max_c = 0, reduce_floats = 0, dgrad_splitk_bytes = 0;
     std::vector<ParamEntry> params;
     std::vector<ParamEntry> bn_entries[4];        // gamma, beta, mean, var (appended after the weights)
     size_t n_floats = 0, n_trainable = 0, G = 0;
@@ -113,8 +131,6 @@ struct Net {
         return off;
     }
 };
-
-struct TensorRef { long off; size_t size; int N, H, W, C; };
 
 static TensorRef new_tensor(Arena& ar, int N, int H, int W, int C) {
     TensorRef t;
@@ -173,7 +189,9 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
         const long w = (long)net->add_param(R + "conv1/weights", PK_CONV_W, 64, 7, 7, net->in_ch_pad, in_ch);
         const long b = (long)net->add_param(R + "conv1/biases", PK_BIAS, 64, 0, 0, 0, 0);
         net->steps.push_back(conv_step(*net, xin, c1, 7, 2, 3, w, b, NONE, nullptr, 1, in_ch));
+        net->w_stem = w; net->b_stem = b;
     }
+    net->t_xin = xin; net->t_c1 = c1;
     done(xin);
     add_tap(*net, "conv1", c1);
     int pt, pl, H2, W2;
@@ -188,6 +206,7 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
     }
     done(c1);
     add_tap(*net, "pool1", cur);
+    net->t_pool = cur; net->pool_pt = pt; net->pool_pl = pl;
 
     struct Blk { const char* name; int depth, dbn, units, stride; };
     const Blk blocks[4] = {{"block1", 256, 64, 3, 2}, {"block2", 512, 128, 4, 2}, {"block3", 1024, 256, 6, 2},
@@ -198,6 +217,10 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             const std::string S = R + b.name + "/unit_" + std::to_string(u) + "/bottleneck_v2/";
             const int cin = cur.C;
             const long bn_pre = net->add_bn(S + "preact", cin);
+            net->bns.push_back({bn_pre, cin, cur.off, (long)N * cur.H * cur.W, cur.H, cur.W});
+            UnitInfo ui{};
+            ui.x = cur; ui.stride = stride; ui.cin = cin; ui.dbn = b.dbn; ui.depth = b.depth; ui.bn_pre = bn_pre;
+            ui.w_sc = ui.b_sc = NONE;
             const int Ho = (cur.H + 2 - 3) / stride + 1, Wo = (cur.W + 2 - 3) / stride + 1;
             TensorRef sc = cur;
             bool own_sc = false;
@@ -207,27 +230,39 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
                 const long w = (long)net->add_param(S + "shortcut/weights", PK_CONV_W, b.depth, 1, 1, cin, cin);
                 const long bb = (long)net->add_param(S + "shortcut/biases", PK_BIAS, b.depth, 0, 0, 0, 0);
                 net->steps.push_back(conv_step(*net, cur, sc, 1, 1, 0, w, bb, bn_pre, nullptr, 1));
+                ui.w_sc = w; ui.b_sc = bb;
             }
             TensorRef r1 = new_tensor(ar, N, cur.H, cur.W, b.dbn);
             {
                 const long w = (long)net->add_param(S + "conv1/weights", PK_CONV_W, b.dbn, 1, 1, cin, cin);
                 net->steps.push_back(conv_step(*net, cur, r1, 1, 1, 0, w, NONE, bn_pre, nullptr, 1));
+                ui.w1 = w;
             }
             const long bn1 = net->add_bn(S + "conv1/BatchNorm", b.dbn);
+            net->bns.push_back({bn1, b.dbn, r1.off, (long)N * r1.H * r1.W, r1.H, r1.W});
             TensorRef r2 = new_tensor(ar, N, Ho, Wo, b.dbn);
             {
                 const long w = (long)net->add_param(S + "conv2/weights", PK_CONV_W, b.dbn, 3, 3, b.dbn, b.dbn);
                 net->steps.push_back(conv_step(*net, r1, r2, 3, stride, 1, w, NONE, bn1, nullptr, 1));
+                ui.w2 = w;
             }
             done(r1);
             const long bn2 = net->add_bn(S + "conv2/BatchNorm", b.dbn);
+            net->bns.push_back({bn2, b.dbn, r2.off, (long)N * r2.H * r2.W, r2.H, r2.W});
             TensorRef nxt = new_tensor(ar, N, Ho, Wo, b.depth);
             {
                 const long w = (long)net->add_param(S + "conv3/weights", PK_CONV_W, b.depth, 1, 1, b.dbn, b.dbn);
                 const long bb = (long)net->add_param(S + "conv3/biases", PK_BIAS, b.depth, 0, 0, 0, 0);
                 // identity shortcut of a strided unit = subsample(x, stride): read the residual at (oy*s, ox*s)
                 net->steps.push_back(conv_step(*net, r2, nxt, 1, 1, 0, w, bb, bn2, &sc, own_sc ? 1 : stride));
+                ui.w3 = w; ui.b3 = bb;
             }
+            ui.sc = sc; ui.r1 = r1; ui.r2 = r2; ui.out = nxt; ui.proj = own_sc; ui.bn1 = bn1; ui.bn2 = bn2;
+            net->units.push_back(ui);
+            net->max_net = std::max({net->max_net, cur.size, nxt.size, sc.size});
+            net->max_r = std::max({net->max_r, r1.size, r2.size});
+            net->max_w = std::max({net->max_w, (size_t)b.dbn * 9 * b.dbn, (size_t)b.depth * cin, (size_t)b.depth * b.dbn});
+            net->max_c = std::max({net->max_c, (size_t)b.depth, (size_t)cin});
             done(r2);
             if (own_sc) done(sc);
             done(cur);
@@ -237,7 +272,10 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
     }
     net->feat_H = cur.H; net->feat_W = cur.W;
     const long bn_post = net->add_bn(R + "postnorm", cur.C);
+    net->bns.push_back({bn_post, cur.C, cur.off, (long)N * cur.H * cur.W, cur.H, cur.W});
+    net->bn_post = bn_post; net->t_last = cur;
     TensorRef g = new_tensor(ar, N, 1, 1, cur.C);
+    net->t_gap = g;
     {
         Step s{};
         s.kind = S_GAP; s.in_off = cur.off; s.out_off = g.off; s.bn_off = bn_post; s.N = N; s.H = cur.H; s.W = cur.W; s.C = cur.C;
@@ -255,6 +293,7 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
         s.b_off = (long)net->add_param("fc/fc/fc_" + std::to_string(k) + "/biases", PK_FC_B, dims[k], 0, 0, 0, 0);
         net->steps.push_back(s);
         net->flops += 2.0 * N * dims[k - 1] * dims[k];
+        net->t_fc[k - 1] = o; net->fc_w[k - 1] = s.w_off; net->fc_b[k - 1] = s.b_off;
         done(f);
         f = o;
     }
@@ -265,7 +304,10 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
         s.b_off = (long)net->add_param("fc/fc_bias", PK_FC_B, n_theta, 0, 0, 0, 0);
         net->steps.push_back(s);
         net->flops += 2.0 * N * 512 * n_theta;
+        net->fc_w[3] = s.w_off; net->fc_b[3] = s.b_off;
     }
+    for (int k = 0; k < 4; ++k) net->fc_dims[k] = dims[k];
+    net->fc_dims[4] = n_theta;
     // BN sections
     net->off_gamma = net->n_floats;
     net->off_beta = net->off_gamma + net->G;
@@ -280,6 +322,7 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             net->params.push_back(e);
         }
     net->act_floats = ar.peak;
+    net->max_net = std::max({net->max_net, net->t_c1.size, net->t_pool.size});
     return net;
 }
 
@@ -558,6 +601,260 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
         if (!last) cur = frame_fb;
     }
     return STABNET_OK;
+}
+
+}  // extern "C"
+
+// =========================================================================================================
+// Training: one tower's forward with batch-statistics BN and the explicit backward schedule
+// (what `opt.minimize(total_loss)` differentiates for get_resnet(is_training=True), s_net_bundle_nobm.py:301,
+// train_bundle_nobm.py:155-160).  The plan must have been created with keep_activations = 1.
+// =========================================================================================================
+struct TrainLayout {
+    size_t bn_scale, bn_shift, bn_mean, bn_invstd, GA, GB, T1, T2, T3, fcg0, fcg1, partial, coef, wt, splitk, total;
+    size_t splitk_bytes;
+};
+
+static size_t rnd64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+static ConvArgs dgrad_args(int N, int H, int W, int Cin, int Cout, int KH, int stride, int pad) {
+    ConvArgs a{};
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KH) / stride + 1;
+    a.N = N; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Cout = Cin; a.KH = KH; a.KW = KH; a.stride = 1; a.pad = KH - 1 - pad;
+    a.up = stride; a.Ho = H; a.Wo = W; a.res_H = H; a.res_W = W; a.res_stride = 1;
+    return a;
+}
+
+static TrainLayout train_layout(const Net* net) {
+    TrainLayout L{};
+    size_t o = rnd64(net->act_floats);
+    auto take = [&](size_t n) { const size_t r = o; o += rnd64(n); return r; };
+    L.bn_scale = take(net->G); L.bn_shift = take(net->G); L.bn_mean = take(net->G); L.bn_invstd = take(net->G);
+    L.GA = take(net->max_net); L.GB = take(net->max_net); L.T1 = take(net->max_r); L.T2 = take(net->max_r);
+    L.T3 = take(net->max_net);
+    L.fcg0 = take((size_t)net->N * 2048); L.fcg1 = take((size_t)net->N * 2048);
+    size_t red = 0;
+    for (const BnInfo& b : net->bns) red = std::max(red, col_reduce_workspace_floats(b.M, b.C));
+    for (const UnitInfo& u : net->units)
+        red = std::max(red, col_reduce_workspace_floats((long)u.out.N * u.out.H * u.out.W, u.depth));
+    red = std::max(red, col_reduce_workspace_floats((long)net->t_c1.N * net->t_c1.H * net->t_c1.W, 64));
+    L.partial = take(red);
+    L.coef = take(3 * std::max<size_t>(net->max_c, 2048));
+    L.wt = take(net->max_w);
+    size_t sk = net->splitk_bytes;
+    for (const UnitInfo& u : net->units) {
+        ConvArgs a3 = dgrad_args(u.r2.N, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0);
+        ConvArgs a2 = dgrad_args(u.r1.N, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, u.stride, 1);
+        ConvArgs a1 = dgrad_args(u.x.N, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 0);
+        ConvArgs as = dgrad_args(u.x.N, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 0);
+        sk = std::max({sk, conv_plan(a3), conv_plan(a2), conv_plan(a1), u.proj ? conv_plan(as) : (size_t)0});
+    }
+    L.splitk_bytes = sk;
+    L.splitk = take(sk / sizeof(float) + 64);
+    L.total = o;
+    return L;
+}
+
+static const BnInfo* find_bn(const Net* net, long chan_off) {
+    for (const BnInfo& b : net->bns)
+        if (b.chan_off == chan_off) return &b;
+    return nullptr;
+}
+
+static int run_forward_train(const Net* net, float* params, const float* x, float* theta, float* ws, float eps,
+                             float decay, hipStream_t st, Prof* prof) {
+    const TrainLayout L = train_layout(net);
+    float* scale = ws + L.bn_scale;
+    float* shift = ws + L.bn_shift;
+    float* splitk = ws + L.splitk;
+    std::vector<char> have(net->bns.size(), 0);
+    auto need_bn = [&](long chan_off) -> int {
+        const BnInfo* b = find_bn(net, chan_off);
+        SN_REQUIRE(b != nullptr, "forward_train: unknown BN at channel offset %ld", chan_off);
+        const size_t idx = (size_t)(b - net->bns.data());
+        if (have[idx]) return STABNET_OK;
+        have[idx] = 1;
+        return launch_bn_stats(ws + b->tensor_off, b->M, b->C, params + net->off_gamma + chan_off,
+                               params + net->off_beta + chan_off, eps, decay, scale + chan_off, shift + chan_off,
+                               ws + L.bn_mean + chan_off, ws + L.bn_invstd + chan_off, params + net->off_mean + chan_off,
+                               params + net->off_var + chan_off, ws + L.partial, st);
+    };
+    for (const Step& s : net->steps) {
+        int rc = STABNET_OK;
+        switch (s.kind) {
+            case S_PAD:
+                rc = launch_pad_channels(x, ws + s.out_off, (long)s.N * s.H * s.W, s.C, net->in_ch_pad, st);
+                break;
+            case S_CONV: {
+                if (s.bn_off >= 0 && (rc = need_bn(s.bn_off)) != 0) return rc;
+                ConvArgs a = s.conv;
+                a.x = ws + s.in_off; a.y = ws + s.out_off; a.w = params + s.w_off;
+                a.bias = s.b_off >= 0 ? params + s.b_off : nullptr;
+                a.residual = s.res_off >= 0 ? ws + s.res_off : nullptr;
+                a.in_scale = s.bn_off >= 0 ? scale + s.bn_off : nullptr;
+                a.in_shift = s.bn_off >= 0 ? shift + s.bn_off : nullptr;
+                a.partial = splitk;
+                rc = conv_launch(a, st, prof);
+                break;
+            }
+            case S_POOL:
+                rc = launch_max_pool(ws + s.in_off, ws + s.out_off, s.N, s.H, s.W, s.C, s.Ho, s.Wo, s.k, s.stride, s.pt, s.pl, st);
+                break;
+            case S_GAP:
+                if ((rc = need_bn(s.bn_off)) != 0) return rc;
+                rc = launch_gap_bn_relu(ws + s.in_off, scale + s.bn_off, shift + s.bn_off, s.N, s.H * s.W, s.C, ws + s.out_off, st);
+                break;
+            case S_FC:
+                rc = launch_fc(ws + s.in_off, params + s.w_off, params + s.b_off,
+                               s.out_off == EXT_OUT ? theta : ws + s.out_off, s.M, s.K, s.Nout, s.relu, st);
+                break;
+        }
+        if (rc) return rc;
+    }
+    return STABNET_OK;
+}
+
+static int run_backward(const Net* net, const float* params, const float* d_theta, float* grads, float* ws,
+                        hipStream_t st, Prof* prof) {
+    const TrainLayout L = train_layout(net);
+    const float* scale = ws + L.bn_scale;
+    const float* shift = ws + L.bn_shift;
+    const float* bmean = ws + L.bn_mean;
+    const float* binv = ws + L.bn_invstd;
+    float* partial = ws + L.partial;
+    float* coef = ws + L.coef;
+    float* wt = ws + L.wt;
+    float* splitk = ws + L.splitk;
+    const int N = net->N;
+    int rc;
+    auto bn_bwd = [&](long bn, const TensorRef& xt, const float* g, const float* addend, int add_stride, float* dx) -> int {
+        return launch_bn_relu_bwd(ws + xt.off, g, scale + bn, shift + bn, bmean + bn, binv + bn, params + net->off_gamma + bn,
+                                  (long)xt.N * xt.H * xt.W, xt.C, addend, add_stride, xt.H, xt.W, grads + net->off_gamma + bn,
+                                  grads + net->off_beta + bn, dx, partial, coef, st);
+    };
+    // ---- FC head (resnet.py:44-56, s_net_bundle_nobm.py:256-259)
+    float* fg[2] = {ws + L.fcg0, ws + L.fcg1};
+    const TensorRef* fin[4] = {&net->t_gap, &net->t_fc[0], &net->t_fc[1], &net->t_fc[2]};
+    const float* dy = d_theta;
+    for (int k = 3; k >= 0; --k) {
+        const float* yk = (k < 3) ? ws + net->t_fc[k].off : nullptr;            // output of layer k (ReLU mask), k < 3
+        float* dx = fg[k & 1];
+        rc = launch_fc_bwd(ws + fin[k]->off, params + net->fc_w[k], yk, dy, N, net->fc_dims[k], net->fc_dims[k + 1], k < 3,
+                           grads + net->fc_w[k], grads + net->fc_b[k], dx, st);
+        if (rc) return rc;
+        dy = dx;
+    }
+    // ---- reduce_mean + postnorm BN + ReLU
+    float* GA = ws + L.GA;
+    float* GB = ws + L.GB;
+    float* T1 = ws + L.T1;
+    float* T2 = ws + L.T2;
+    float* T3 = ws + L.T3;
+    const TensorRef& last = net->t_last;
+    if ((rc = launch_gap_bwd(dy, N, last.H * last.W, last.C, T3, st)) != 0) return rc;
+    if ((rc = bn_bwd(net->bn_post, last, T3, nullptr, 1, GA)) != 0) return rc;
+    // ---- bottleneck units, last to first.  G = d(unit output)
+    for (int ui = (int)net->units.size() - 1; ui >= 0; --ui) {
+        const UnitInfo& u = net->units[ui];
+        const long Mo = (long)u.out.N * u.out.H * u.out.W;
+        float* G = GA;
+        // conv3 (1x1, bias) : input relu(bn2(r2))
+        if ((rc = launch_bias_grad(G, Mo, u.depth, grads + u.b3, partial, st)) != 0) return rc;
+        if ((rc = wgrad_launch(ws + u.r2.off, G, grads + u.w3, scale + u.bn2, shift + u.bn2, N, u.r2.H, u.r2.W, u.dbn, u.depth,
+                               1, 1, 1, 0, st, prof)) != 0) return rc;
+        if ((rc = pack_dgrad_weights(params + u.w3, wt, u.depth, 1, 1, u.dbn, st)) != 0) return rc;
+        if ((rc = dgrad_launch(G, wt, T1, nullptr, N, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
+        if ((rc = bn_bwd(u.bn2, u.r2, T1, nullptr, 1, T1)) != 0) return rc;                      // T1 = d r2
+        // conv2 (3x3, stride) : input relu(bn1(r1))
+        if ((rc = wgrad_launch(ws + u.r1.off, T1, grads + u.w2, scale + u.bn1, shift + u.bn1, N, u.r1.H, u.r1.W, u.dbn, u.dbn,
+                               3, 3, u.stride, 1, st, prof)) != 0) return rc;
+        if ((rc = pack_dgrad_weights(params + u.w2, wt, u.dbn, 3, 3, u.dbn, st)) != 0) return rc;
+        if ((rc = dgrad_launch(T1, wt, T2, nullptr, N, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, 3, u.stride, 1, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
+        if ((rc = bn_bwd(u.bn1, u.r1, T2, nullptr, 1, T2)) != 0) return rc;                      // T2 = d r1
+        // conv1 (1x1) : input relu(bn_pre(x))
+        if ((rc = wgrad_launch(ws + u.x.off, T2, grads + u.w1, scale + u.bn_pre, shift + u.bn_pre, N, u.x.H, u.x.W, u.cin, u.dbn,
+                               1, 1, 1, 0, st, prof)) != 0) return rc;
+        if ((rc = pack_dgrad_weights(params + u.w1, wt, u.dbn, 1, 1, u.cin, st)) != 0) return rc;
+        if ((rc = dgrad_launch(T2, wt, T3, nullptr, N, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
+        if (u.proj) {   // projection shortcut conv1x1(preact) + bias: d preact += dgrad(G)
+            if ((rc = launch_bias_grad(G, Mo, u.depth, grads + u.b_sc, partial, st)) != 0) return rc;
+            if ((rc = wgrad_launch(ws + u.x.off, G, grads + u.w_sc, scale + u.bn_pre, shift + u.bn_pre, N, u.x.H, u.x.W, u.cin,
+                                   u.depth, 1, 1, 1, 0, st, prof)) != 0) return rc;
+            if ((rc = pack_dgrad_weights(params + u.w_sc, wt, u.depth, 1, 1, u.cin, st)) != 0) return rc;
+            if ((rc = dgrad_launch(G, wt, T3, T3, N, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
+            if ((rc = bn_bwd(u.bn_pre, u.x, T3, nullptr, 1, GB)) != 0) return rc;
+        } else {        // identity shortcut (subsample by the unit's stride): d x += upsample(G)
+            if ((rc = bn_bwd(u.bn_pre, u.x, T3, G, u.stride, GB)) != 0) return rc;
+        }
+        std::swap(GA, GB);
+    }
+    // ---- stem: max-pool backward, conv1 weight/bias gradient (the input needs no gradient)
+    const TensorRef& c1 = net->t_c1;
+    const TensorRef& pl = net->t_pool;
+    if ((rc = launch_max_pool_bwd(ws + c1.off, GA, GB, N, c1.H, c1.W, c1.C, pl.H, pl.W, 3, 2, net->pool_pt, net->pool_pl, st)) != 0) return rc;
+    if ((rc = launch_bias_grad(GB, (long)N * c1.H * c1.W, 64, grads + net->b_stem, partial, st)) != 0) return rc;
+    return wgrad_launch(ws + net->t_xin.off, GB, grads + net->w_stem, nullptr, nullptr, N, net->H, net->W, net->in_ch_pad, 64, 7,
+                        7, 2, 3, st, prof);
+}
+
+extern "C" {
+
+/* Bytes of one tower's training workspace (activations kept for backward + batch BN buffers + gradient scratch). */
+size_t stabnet_net_train_workspace_bytes(const void* netp) {
+    const Net* net = static_cast<const Net*>(netp);
+    if (!net || !net->keep_all) return 0;
+    return train_layout(net).total * sizeof(float) + 256;
+}
+
+/* get_resnet(x_tensor, is_training=True): batch-statistics BN; moving averages inside `params` are updated
+ * (slim UPDATE_OPS, s_net_bundle_nobm.py:355-356).  Activations stay in `workspace` for stabnet_tower_bwd. */
+int stabnet_tower_fwd_train(const void* netp, float* params, const float* x_tensor, float* theta, void* workspace,
+                            size_t workspace_bytes, float bn_eps, float bn_decay, void* stream, void* prof) {
+    const Net* net = static_cast<const Net*>(netp);
+    SN_REQUIRE(net && params && x_tensor && theta && workspace, "tower_fwd_train: null pointer");
+    SN_REQUIRE(net->keep_all, "tower_fwd_train: the plan must be created with keep_activations = 1");
+    SN_REQUIRE(workspace_bytes >= stabnet_net_train_workspace_bytes(netp), "tower_fwd_train: workspace too small");
+    return run_forward_train(net, params, x_tensor, theta, static_cast<float*>(workspace), bn_eps, bn_decay,
+                             (hipStream_t)stream, static_cast<Prof*>(prof));
+}
+
+/* Backward of the tower given d_theta [N,n_theta]; gradients are ACCUMULATED into `grads` (same layout as the
+ * trainable prefix of `params`; zero it once per step -- both siamese towers add into it). */
+int stabnet_tower_bwd(const void* netp, const float* params, const float* d_theta, float* grads, void* workspace,
+                      size_t workspace_bytes, void* stream, void* prof) {
+    const Net* net = static_cast<const Net*>(netp);
+    SN_REQUIRE(net && params && d_theta && grads && workspace, "tower_bwd: null pointer");
+    SN_REQUIRE(net->keep_all, "tower_bwd: the plan must be created with keep_activations = 1");
+    SN_REQUIRE(workspace_bytes >= stabnet_net_train_workspace_bytes(netp), "tower_bwd: workspace too small");
+    return run_backward(net, params, d_theta, grads, static_cast<float*>(workspace), (hipStream_t)stream,
+                        static_cast<Prof*>(prof));
+}
+
+/* Batch-statistics view of a tower's last forward: folded (scale, shift) [2][G] copied out for inspection/tests. */
+int stabnet_net_train_bn_offsets(const void* netp, long* scale_off, long* shift_off, long* mean_off, long* invstd_off) {
+    const Net* net = static_cast<const Net*>(netp);
+    SN_REQUIRE(net && scale_off && shift_off && mean_off && invstd_off, "train_bn_offsets: null pointer");
+    const TrainLayout L = train_layout(net);
+    *scale_off = (long)L.bn_scale; *shift_off = (long)L.bn_shift; *mean_off = (long)L.bn_mean; *invstd_off = (long)L.bn_invstd;
+    return STABNET_OK;
+}
+
+/* slim L2 regularisers (s_net_bundle_nobm.py:324-325; resnet.py:35-37): value = sum_seg coef*0.5*sum w^2 added to
+ * *loss_out (zero it first; may be NULL); grads[seg] += gscale*coef*w (grads may be NULL).  seg_* are DEVICE arrays. */
+int stabnet_weight_decay(const float* params, float* grads, const long* seg_off, const long* seg_len,
+                         const float* seg_coef, int nseg, float gscale, float* loss_out, void* stream) {
+    SN_REQUIRE(params && seg_off && seg_len && seg_coef && nseg > 0 && nseg <= 65535, "weight_decay: bad arguments");
+    return launch_weight_decay(params, grads, seg_off, seg_len, seg_coef, nseg, gscale, loss_out, (hipStream_t)stream);
+}
+
+/* tf.train.AdamOptimizer.apply_gradients (train_bundle_nobm.py:159-160): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_t m / (sqrt(v) + eps).  g is scaled by gscale first
+ * (1/world for data-parallel averaging); g = grads + grads2 when grads2 is given (one buffer per siamese tower). */
+int stabnet_adam_step(float* params, const float* grads, const float* grads2, float* m, float* v, long n, float lr,
+                      float beta1, float beta2, float eps, int step, float gscale, void* stream) {
+    SN_REQUIRE(params && grads && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+    return launch_adam(params, grads, grads2, m, v, n, (float)lr_t, beta1, beta2, eps, gscale, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -19,8 +19,8 @@ int launch_fc_bwd(const float* x, const float* w, const float* y, const float* d
                   float* dW, float* db, float* dx, hipStream_t st);
 int launch_weight_decay(const float* params, float* grads, const long* seg_off, const long* seg_len, const float* seg_coef,
                         int nseg, float gscale, float* loss_out, hipStream_t st);
-int launch_adam(float* w, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
-                float gscale, hipStream_t st);
+int launch_adam(float* w, const float* g, const float* g2, float* m, float* v, long n, float lr_t, float b1, float b2,
+                float eps, float gscale, hipStream_t st);
 
 int wgrad_launch(const float* x, const float* dy, float* dw, const float* in_scale, const float* in_shift, int N, int H,
                  int W, int Cin, int Cout, int KH, int KW, int stride, int pad, hipStream_t st, Prof* prof);

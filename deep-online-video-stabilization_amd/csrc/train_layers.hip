@@ -286,7 +286,8 @@ __global__ __launch_bounds__(256) void weight_decay_kernel(const float* __restri
 
 // tf.train.AdamOptimizer step (TF 1.x): lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);
 // m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  w -= lr_t * m / (sqrt(v) + eps).   g is multiplied by gscale first.
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                   const float* __restrict__ g2, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float lr_t, float b1, float b2,
                                                    float eps, float gscale) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -294,6 +295,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
     if (i + 3 < n) {
         float4 wv = *reinterpret_cast<float4*>(w + i), mv = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
         float4 gv = *reinterpret_cast<const float4*>(g + i);
+        if (g2 != nullptr) {
+            const float4 hv = *reinterpret_cast<const float4*>(g2 + i);
+            gv.x += hv.x; gv.y += hv.y; gv.z += hv.z; gv.w += hv.w;
+        }
         gv.x *= gscale; gv.y *= gscale; gv.z *= gscale; gv.w *= gscale;
         mv.x = b1 * mv.x + (1.f - b1) * gv.x; mv.y = b1 * mv.y + (1.f - b1) * gv.y;
         mv.z = b1 * mv.z + (1.f - b1) * gv.z; mv.w = b1 * mv.w + (1.f - b1) * gv.w;
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
         *reinterpret_cast<float4*>(w + i) = wv; *reinterpret_cast<float4*>(m + i) = mv; *reinterpret_cast<float4*>(v + i) = vv;
     } else {
         for (long j = i; j < n; ++j) {
-            const float gg = g[j] * gscale;
+            const float gg = (g[j] + (g2 != nullptr ? g2[j] : 0.f)) * gscale;
             m[j] = b1 * m[j] + (1.f - b1) * gg;
             v[j] = b2 * v[j] + (1.f - b2) * gg * gg;
             w[j] -= lr_t * m[j] / (sqrtf(v[j]) + eps);
@@ -403,9 +408,9 @@ int launch_weight_decay(const float* params, float* grads, const long* seg_off, 
     return STABNET_OK;
 }
 
-int launch_adam(float* w, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
-                float gscale, hipStream_t st) {
-    adam_kernel<<<cdiv((n + 3) / 4, 256), 256, 0, st>>>(w, g, m, v, n, lr_t, b1, b2, eps, gscale);
+int launch_adam(float* w, const float* g, const float* g2, float* m, float* v, long n, float lr_t, float b1, float b2,
+                float eps, float gscale, hipStream_t st) {
+    adam_kernel<<<cdiv((n + 3) / 4, 256), 256, 0, st>>>(w, g, g2, m, v, n, lr_t, b1, b2, eps, gscale);
     SN_LAUNCH_CHECK("adam_kernel");
     return STABNET_OK;
 }

@@ -457,17 +457,31 @@ int stabnet_transformer_bwd(const float* pts2, const float* Hs, const float* U, 
 
 /* interpolate(im, x, y) backward wrt im (train_bundle_nobm.py:117: the gradient that reaches tower 2's output). */
 int stabnet_interp_bwd(const float* x, const float* y, const float* d_out, int N, int H, int W, int C, float* d_im,
-                       void* stream) {
+                       int accumulate, void* stream) {
     SN_REQUIRE(x && y && d_out && d_im, "interp_bwd: null pointer");
     SN_REQUIRE(N > 0 && N <= 65535 && H > 0 && W > 0 && C > 0, "interp_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(d_im, 0, sizeof(float) * (size_t)N * H * W * C, st) != hipSuccess) {
+    if (!accumulate && hipMemsetAsync(d_im, 0, sizeof(float) * (size_t)N * H * W * C, st) != hipSuccess) {
         stabnet_set_error("interp_bwd: memset failed");
         return STABNET_ERR_LAUNCH;
     }
     dim3 grid(cdiv(W, 256), cdiv(H, 4), N);
     interp_bwd_kernel<<<grid, 256, 0, st>>>(x, y, d_out, H, W, C, d_im);
     SN_LAUNCH_CHECK("interp_bwd_kernel");
+    return STABNET_OK;
+}
+
+__global__ __launch_bounds__(256) void axpb_kernel(const float* __restrict__ x, float a, float b, long n,
+                                                   float* __restrict__ y) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = a * x[i] + b;
+}
+
+/* y = a*x + b elementwise (e.g. 1 - black_pix, train_bundle_nobm.py:118). */
+int stabnet_axpb(const float* x, float a, float b, long n, float* y, void* stream) {
+    SN_REQUIRE(x && y && n > 0, "axpb: bad arguments");
+    axpb_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(x, a, b, n, y);
+    SN_LAUNCH_CHECK("axpb_kernel");
     return STABNET_OK;
 }
 

@@ -19,12 +19,23 @@ def transformer_bwd(pts2, Hs, U, x_map, y_map, d_out=None, d_xmap=None, d_ymap=N
     return d_pts2
 
 
-def interp_bwd(x, y, d_out):
+def interp_bwd(x, y, d_out, d_im=None):
+    """d_im (+)= scatter of d_out; a given d_im is accumulated into."""
     d_out = dev_f32(d_out, "d_out")
     N, H, W, C = d_out.shape
-    d_im = empty((N, H, W, C), d_out)
-    _lib.call("stabnet_interp_bwd", ptr(dev_f32(x)), ptr(dev_f32(y)), ptr(d_out), N, H, W, C, ptr(d_im), stream_ptr())
+    acc = d_im is not None
+    if d_im is None:
+        d_im = empty((N, H, W, C), d_out)
+    _lib.call("stabnet_interp_bwd", ptr(dev_f32(x)), ptr(dev_f32(y)), ptr(d_out), N, H, W, C, ptr(d_im), int(acc),
+              stream_ptr())
     return d_im
+
+
+def axpb(x, a, b):
+    x = dev_f32(x)
+    y = torch.empty_like(x)
+    _lib.call("stabnet_axpb", ptr(x), float(a), float(b), x.numel(), ptr(y), stream_ptr())
+    return y
 
 
 def masked_mse_sums(a, b, black, m2=None):

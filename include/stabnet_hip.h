@@ -145,9 +145,12 @@ int stabnet_transformer_bwd(const float* pts2, const float* Hs, const float* U, 
                             const float* d_out, const float* d_xmap, const float* d_ymap, int N, int H, int W, int C,
                             int grid_h, int grid_w, float* d_pts2, void* workspace, void* stream);
 
-/* d interpolate(im, x, y) / d im  (train_bundle_nobm.py:117-118): scatter-add of the four taps; d_im is zeroed here. */
+/* d interpolate(im, x, y) / d im  (train_bundle_nobm.py:117-118): scatter-add of the four taps; d_im is zeroed first unless accumulate. */
 int stabnet_interp_bwd(const float* x, const float* y, const float* d_out, int N, int H, int W, int C, float* d_im,
-                       void* stream);
+                       int accumulate, void* stream);
+
+/* y = a*x + b elementwise (1 - black_pix of train_bundle_nobm.py:118). */
+int stabnet_axpb(const float* x, float a, float b, long n, float* y, void* stream);
 
 /* masked MSE of img_loss (s_net_bundle_nobm.py:347-352, m2 = NULL) and temp_loss (train_bundle_nobm.py:110-125,
  * m2 = interp(1 - black2)): sums [N,2] = {sum((a-b)m)^2, sum m}, m = (1 - black) * m2;
@@ -184,6 +187,33 @@ size_t stabnet_conv2d_dgrad_workspace_bytes(int N, int H, int W, int Cin, int Co
 int stabnet_conv2d_dgrad(const float* dy, const float* w_ohwi, float* dx, const float* residual, int N, int H, int W,
                          int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,
                          size_t workspace_bytes, void* stream);
+
+/* ---- training: the regressor tower (get_resnet(is_training=True) and its autodiff) -------------------------
+ * The plan must be created with keep_activations = 1.  One workspace per tower (activations are kept between the
+ * forward and the backward of the same tower; the siamese step runs two towers, train_bundle_nobm.py:107-108). */
+size_t stabnet_net_train_workspace_bytes(const void* net);
+
+/* Forward with batch-statistics BN (tf.nn.moments, biased variance); updates the moving averages stored in `params`
+ * (slim UPDATE_OPS tied to the step, s_net_bundle_nobm.py:355-356).  x_tensor [N,H,W,in_ch] -> theta [N,n_theta]. */
+int stabnet_tower_fwd_train(const void* net, float* params, const float* x_tensor, float* theta, void* workspace,
+                            size_t workspace_bytes, float bn_eps, float bn_decay, void* stream, void* prof);
+
+/* Backward from d_theta [N,n_theta]; parameter gradients are ACCUMULATED into grads (layout = trainable prefix of
+ * params; zero once per step). */
+int stabnet_tower_bwd(const void* net, const float* params, const float* d_theta, float* grads, void* workspace,
+                      size_t workspace_bytes, void* stream, void* prof);
+
+/* Float offsets, inside a tower workspace, of the batch BN buffers [G] (scale, shift, mean, invstd) of the last forward. */
+int stabnet_net_train_bn_offsets(const void* net, long* scale_off, long* shift_off, long* mean_off, long* invstd_off);
+
+/* slim L2 regularisers (REGULARIZATION_LOSSES, s_net_bundle_nobm.py:324-325; resnet.py:35-37): *loss_out +=
+ * sum_seg coef*0.5*sum w^2 (NULL to skip), grads[seg] += gscale*coef*w (NULL to skip).  seg_* are DEVICE arrays. */
+int stabnet_weight_decay(const float* params, float* grads, const long* seg_off, const long* seg_len,
+                         const float* seg_coef, int nseg, float gscale, float* loss_out, void* stream);
+
+/* tf.train.AdamOptimizer step (train_bundle_nobm.py:155-160): g = (grads + grads2) * gscale (grads2 may be NULL). */
+int stabnet_adam_step(float* params, const float* grads, const float* grads2, float* m, float* v, long n, float lr,
+                      float beta1, float beta2, float eps, int step, float gscale, void* stream);
 
 #ifdef __cplusplus
 }

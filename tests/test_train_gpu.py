@@ -1,0 +1,108 @@
+"""GPU: one full siamese training step (two towers, batch-stat BN, warp, all losses, temporal loss, backward, weight
+decay, Adam) against the torch float64 autograd oracle of the reference objective (train_bundle_nobm.py:107-160)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stabnet_oracle as O
+from oracle import torch_ref as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(N, H, W, seed=5):
+    from stabnet_amd import synthetic
+    from stabnet_amd.config import Config
+    cfg = Config(height=H, width=W, batch_size=N, max_matches=48)
+    ocfg = O.Config(height=H, width=W, batch_size=N, max_matches=48)
+    P = synthetic.make_params(cfg, seed=0, theta_scale=0.3)
+    b = synthetic.make_train_batch(cfg, N, H, W, seed)
+    b["flow"] = (b["flow"] + np.random.default_rng(1).normal(0, 0.02, b["flow"].shape)).astype(np.float32)
+    return cfg, ocfg, P, b
+
+
+def test_training_step_matches_autograd_oracle(cuda):
+    from stabnet_amd.train import Trainer
+    N, H, W = 2, 64, 96
+    cfg, ocfg, P, b = _setup(N, H, W)
+    gates = {"use_theta_loss": 1, "use_temp_loss": 1, "use_black_loss": 1, "use_theta_only": 0}
+
+    pt = {k: T.t(v, requires_grad=True) for k, v in P.items()}
+    stats = {}
+    total, parts = T.train_objective(pt, b, ocfg, 1.0, 1.0, 0.0, training=True, batch_stats=stats)
+    total.backward()
+    want_g = {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in pt.items()}
+
+    tr = Trainer(P, N, H, W, cfg, device=cuda)
+    p0 = tr.params.clone()
+    dev_b = {k: torch.from_numpy(v).to(cuda) for k, v in b.items()}
+    tr.forward_backward(dev_b, gates, apply_update=False)
+    torch.cuda.synchronize()
+
+    # forward: theta of both towers and the loss terms
+    for k, key in enumerate(("tower1", "tower2")):
+        assert np.abs(tr.theta[k].cpu().numpy() - parts[key]["theta"].detach().numpy()).max() < 5e-5
+    lo = tr.losses()
+    assert lo["total_loss"] == pytest.approx(float(total), rel=2e-3)
+    assert lo["temp_loss"] == pytest.approx(float(parts["temp_loss"]) * cfg.temp_mul, rel=5e-3, abs=1e-6)
+    assert lo["tower1"]["img_loss"] == pytest.approx(float(parts["tower1"]["img"]) * cfg.img_mul, rel=2e-3)
+    assert lo["tower2"]["feature_loss"] == pytest.approx(float(parts["tower2"]["feature"]), rel=2e-3)
+
+    # backward: every trainable tensor, error relative to that tensor's gradient scale
+    got_flat = (tr.grads[0] + tr.grads[1]).cpu().numpy()
+    want_flat = tr.plan.pack({k: want_g[k] for k in P})[:tr.nt]
+    worst = 0.0
+    gmax = np.abs(want_flat).max()
+    for name, off, kind, dims, aux in tr.plan.table:
+        if kind in (4, 5):
+            continue
+        n = int(np.prod([d for d in dims if d > 0]))
+        gg, ww = got_flat[off:off + n], want_flat[off:off + n]
+        # tensors whose gradient is analytically ~0 (e.g. a bias in front of a batch-stat BN) are judged against the
+        # global gradient scale instead of their own
+        scale = max(np.abs(ww).max(), 1e-5 * gmax)
+        err = np.abs(gg - ww).max() / scale
+        worst = max(worst, err)
+        assert err < 2e-2, "%s: rel err %g (scale %g)" % (name, err, scale)
+    cos = float(np.dot(got_flat, want_flat) / (np.linalg.norm(got_flat) * np.linalg.norm(want_flat)))
+    assert cos > 1 - 1e-5, "gradient cosine %r, worst tensor err %g" % (cos, worst)
+
+    # batch-statistics BN moving averages (decay 0.997), both towers applied
+    q = tr.plan.unpack(tr.params.cpu().numpy())
+    name = "resnet_v2_50/block1/unit_1/bottleneck_v2/preact/moving_mean"
+    m = P[name].astype(np.float64)
+    for key in ("1", "2"):
+        m = m - (m - stats[key][name[:-len("/moving_mean")]][0]) * (1 - cfg.bn_decay)
+    assert np.abs(q[name] - m).max() < 1e-5
+    assert torch.equal(tr.params[:tr.nt], p0[:tr.nt])            # apply_update=False left the trainables alone
+
+    # Adam step 1: |dw| = lr * |g| / (|g| + eps') ~ lr wherever the gradient is not tiny
+    tr2 = Trainer(P, N, H, W, cfg, device=cuda)
+    tr2.forward_backward(dev_b, gates, apply_update=True)
+    dw = (tr2.params[:tr2.nt] - p0[:tr2.nt]).cpu().numpy()
+    g = want_flat
+    big = np.abs(g) > 1e-4
+    assert np.allclose(dw[big], -cfg.initial_learning_rate * np.sign(g[big]), rtol=2e-2, atol=1e-9)
+
+
+def test_theta_only_phase_and_gates(cuda):
+    """i <= do_theta_only_iter: total = theta_loss only (s_net_bundle_nobm.py:357-359)."""
+    from stabnet_amd.train import Trainer, loss_gates, learning_rate
+    N, H, W = 2, 64, 96
+    cfg, ocfg, P, b = _setup(N, H, W)
+    assert loss_gates(0, cfg) == {"use_theta_loss": 1, "use_temp_loss": 0, "use_black_loss": 0, "use_theta_only": 1}
+    assert loss_gates(5000, cfg) == {"use_theta_loss": 1, "use_temp_loss": 1, "use_black_loss": 1, "use_theta_only": 0}
+    assert learning_rate(39999, cfg) == pytest.approx(2e-5) and learning_rate(40000, cfg) == pytest.approx(2e-6)
+    tr = Trainer(P, N, H, W, cfg, device=cuda)
+    dev_b = {k: torch.from_numpy(v).to(cuda) for k, v in b.items()}
+    tr.forward_backward(dev_b, loss_gates(0, cfg), apply_update=False)
+    lo = tr.losses()
+    assert lo["total_loss"] == pytest.approx(lo["tower1"]["theta_loss"] + lo["tower2"]["theta_loss"], rel=1e-6)
+    # only the path to theta has gradient: conv1 weights do, and there is no weight-decay term
+    pt = {k: T.t(v, requires_grad=True) for k, v in P.items()}
+    total, _ = T.train_objective(pt, b, ocfg, 0.0, 0.0, 1.0, training=True)
+    total.backward()
+    want = tr.plan.pack({k: (pt[k].grad.numpy() if pt[k].grad is not None else np.zeros(P[k].shape)) for k in P})[:tr.nt]
+    got = (tr.grads[0] + tr.grads[1]).cpu().numpy()
+    cos = float(np.dot(got, want) / (np.linalg.norm(got) * np.linalg.norm(want)))
+    assert cos > 1 - 1e-5
