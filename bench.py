@@ -40,7 +40,60 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--clip-frames", type=int, default=32)
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer: BASELINE configs[1] (the headline); train: configs[2]/[3], siamese pairs/s")
+    ap.add_argument("--train-batch", type=int, default=8, help="pairs per GPU (weak scaling)")
+    ap.add_argument("--train-height", type=int, default=288)
+    ap.add_argument("--train-width", type=int, default=512)
+    ap.add_argument("--train-steps", type=int, default=10, help="steps of the extra train leg of the default run")
+    ap.add_argument("--no-train-leg", action="store_true")
     return ap.parse_args()
+
+
+def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
+    """BASELINE configs[2]/[3]: one optimiser step = `train_batch` siamese pairs per GPU at 288x512, full forward +
+    backward (incl. warp gradient) + Adam, gradient all-reduce over RCCL when world > 1.  Returns a dict."""
+    from stabnet_amd import synthetic
+    from stabnet_amd.config import Config
+    from stabnet_amd.deploy import Profiler
+    from stabnet_amd.train import Trainer
+    N, H, W = args.train_batch, args.train_height, args.train_width
+    cfg = Config(height=H, width=W, batch_size=N)
+    P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
+    pg = dist.group.WORLD if dist is not None else None
+    tr = Trainer(P, N, H, W, cfg, device=dev, process_group=pg, world_size=world)
+    b = synthetic.make_train_batch(cfg, N, H, W, seed=1234 + rank)
+    dev_b = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+    gates = {"use_theta_loss": 1, "use_temp_loss": 1, "use_black_loss": 1, "use_theta_only": 0}   # late-training values
+    for _ in range(warmup):
+        tr.forward_backward(dev_b, gates)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.forward_backward(dev_b, gates)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+        dist.barrier()
+    out = {"value": steps * N * world / el, "unit": "pairs/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+           "warmup": warmup, "pairs_per_gpu": N, "global_batch": N * world, "height": H, "width": W,
+           "tower_fwd_gflop": tr.plan.flops / 1e9, "loss": tr.losses()["total_loss"] if rank == 0 else None}
+    if with_prof and rank == 0:
+        prof = Profiler(max_records=4 * (steps // 2 + 1) * 600)
+        tr.prof = prof
+        for _ in range(max(1, steps // 2)):
+            tr.forward_backward(dev_b, gates)
+        roof, table = roofline_from_records(prof.records(), max(1, steps // 2))
+        tr.prof = None
+        out["roofline"] = roof
+        out["kernels"] = table[:6]
+    return out
 
 
 def roofline_from_records(recs, steps):
@@ -120,6 +173,26 @@ def main():
     from stabnet_amd.config import Config
     from stabnet_amd.deploy import Profiler, StabNetStream
 
+    if args.mode == "train":
+        t = train_leg(args, dev, dist, rank, world, args.steps, args.warmup, not args.no_roofline)
+        if rank == 0:
+            line = {"metric": "train samples/sec (siamese pairs, 288x512)", "value": t["value"], "unit": "pairs/s",
+                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t["ms_per_step"],
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": "BASELINE.json configs[%d]: train_bundle_nobm step, %d pairs/GPU at %dx%d "
+                                           "(global batch %d), two towers fwd+bwd incl. warp gradient, temporal loss, "
+                                           "Adam; local BN, RCCL gradient all-reduce" % (
+                                               2 if world == 1 else 3, t["pairs_per_gpu"], t["width"], t["height"],
+                                               t["global_batch"]),
+                               "global_batch": t["global_batch"], "parallelism": "dp%d" % world}}
+            for k in ("roofline", "kernels", "loss", "tower_fwd_gflop"):
+                if k in t:
+                    line[k] = t[k]
+            print(json.dumps(line))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
     H, W, S = args.height, args.width, args.streams
     cfg = Config(height=H, width=W)
     P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
@@ -152,6 +225,7 @@ def main():
         el = float(tt.item())
     barrier()
     checksum = float(stream.out_img.double().sum().item())
+    plan_flops, plan_launches = stream.reg.plan.flops, stream.reg.plan.num_launches
 
     roof, table, prof_ms = None, None, None
     if rank == 0 and not args.no_roofline:
@@ -169,6 +243,11 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(P, clip, H, W, args.cpu_baseline_seconds)
+    train = None
+    if not args.no_train_leg:
+        del stream
+        torch.cuda.empty_cache()
+        train = train_leg(args, dev, dist, rank, world, args.train_steps, 3, False)
 
     if dist is not None:
         dist.barrier()
@@ -185,8 +264,8 @@ def main():
                                    "the reference), ResNet-v2-50 regressor + 4x4 multi-grid warp + feedback; one "
                                    "independent stream set per GPU (replicas only)" % (W, H, S, args.before_ch),
                        "height": H, "width": W, "streams_per_gpu": S, "refine": args.refine,
-                       "backbone_gflop_per_frame": stream.reg.plan.flops / 1e9 / S,
-                       "launches_per_frame": stream.reg.plan.num_launches + 4},
+                       "backbone_gflop_per_frame": plan_flops / 1e9 / S,
+                       "launches_per_frame": plan_launches + 4},
             "per_gpu_fps": fps / world, "checksum": checksum,
         }
         if roof is not None:
@@ -195,6 +274,8 @@ def main():
             line["instrumented_ms_per_step"] = prof_ms
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        if train is not None:
+            line["train"] = train          # BASELINE configs[2]/[3] measured in the same run (second metric)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

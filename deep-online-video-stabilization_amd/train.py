@@ -10,7 +10,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib, train_ops, warp
+from . import _lib, parallel, train_ops, warp
 from ._tensor import dev_f32, ptr, stream_ptr
 from .config import Config, v2_93
 from .regressor import KIND_CONV_W, NetPlan
@@ -72,16 +72,18 @@ class Trainer:
         self.world = world_size
         self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
         self.last = None
+        self.prof = None                                        # deploy.Profiler: per-launch HIP events (bench only)
 
     # ------------------------------------------------------------------------------------------------------
     def _tower_fwd(self, k: int, x):
         _lib.call("stabnet_tower_fwd_train", self.plan.handle, ptr(self.params), ptr(x), ptr(self.theta[k]),
-                  ptr(self.ws[k]), self.ws_bytes, self.cfg.bn_eps, self.cfg.bn_decay, stream_ptr(), 0)
+                  ptr(self.ws[k]), self.ws_bytes, self.cfg.bn_eps, self.cfg.bn_decay, stream_ptr(),
+                  self.prof.handle if self.prof is not None else 0)
         return self.theta[k]
 
     def _tower_bwd(self, k: int, d_theta):
         _lib.call("stabnet_tower_bwd", self.plan.handle, ptr(self.params), ptr(d_theta), ptr(self.grads[k]),
-                  ptr(self.ws[k]), self.ws_bytes, stream_ptr(), 0)
+                  ptr(self.ws[k]), self.ws_bytes, stream_ptr(), self.prof.handle if self.prof is not None else 0)
 
     def _allreduce_async(self, k: int):
         """Sum tower k's gradient buffer over ranks on the communication stream (overlaps the next backward)."""
@@ -90,10 +92,9 @@ class Trainer:
         import torch.distributed as dist
         self.comm_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm_stream):
-            nb = 4                                              # a few large buckets: xGMI rings are per-link bound
-            per = (self.nt + nb - 1) // nb
-            for b in range(nb):
-                dist.all_reduce(self.grads[k][b * per:min(self.nt, (b + 1) * per)], group=self.pg)
+            # a few large buckets: xGMI is point-to-point, rings are per-link bound -> few big messages
+            for lo, hi in parallel.bucket_bounds(self.nt, 4):
+                dist.all_reduce(self.grads[k][lo:hi], group=self.pg)
 
     def forward_backward(self, batch: dict, gates: dict = None, apply_update: bool = True):
         """One optimiser step on a batch dict (x1,y1,x2,y2,flow,matches1,mask1,matches2,mask2), device tensors.

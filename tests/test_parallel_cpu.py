@@ -1,0 +1,59 @@
+"""CPU, world_size 2 over gloo: the data-parallel host logic (sample sharding + bucketed gradient sum) gives the same
+averaged gradient as one process on the global batch, for a loss that is a mean over samples."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port)})
+    import torch.distributed as dist
+    from stabnet_amd import parallel
+    pg = parallel.init_process_group("gloo")
+    assert parallel.env_world() == (rank, rank, world)
+    rng = np.random.default_rng(0)
+    X = torch.tensor(rng.standard_normal((5, 7)))            # 5 samples: uneven shards (3 + 2)
+    w = torch.tensor(rng.standard_normal(7), requires_grad=True)
+    local = parallel.shard_batch({"x": X}, rank, world)["x"]
+    loss = ((local @ w) ** 2).sum() / X.shape[0]             # per-sample terms divided by the GLOBAL batch
+    loss.backward()
+    flat = torch.cat([w.grad, torch.zeros(1000003, dtype=w.grad.dtype)])      # odd length: exercises bucket bounds
+    parallel.allreduce_sum_(flat, pg, n_buckets=4)
+    q.put((rank, flat[:7].numpy().copy(), float(flat[7:].abs().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_sum_equals_global_batch():
+    from stabnet_amd import parallel
+    assert [parallel.shard_range(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+    assert [parallel.shard_range(64, r, 8) for r in range(8)][-1] == (56, 64)
+    assert parallel.bucket_bounds(10, 4) == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(0)
+    X = torch.tensor(rng.standard_normal((5, 7)))
+    w = torch.tensor(rng.standard_normal(7), requires_grad=True)
+    (((X @ w) ** 2).sum() / 5).backward()
+    for rank, g, tail in res:
+        assert np.allclose(g, w.grad.numpy(), rtol=1e-12, atol=1e-12) and tail == 0.0
