@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Online stabilisation driver on MI355X -- drop-in for the reference's deploy_bundle.py call surface.
+
+Same flags as the reference CLI (deploy_bundle.py:12-31).  What runs on the GPU is the part the reference times
+(deploy_bundle.py:285-287): 13-channel stack -> regressor -> multi-grid warp, plus the history ring and the feedback,
+which the reference does in NumPy on the host.  Differences forced by the offline image, stated rather than hidden:
+  * TensorFlow checkpoints / .meta graphs cannot be read here: --model-dir/--model-name take a `.npz` written by
+    train_bundle_nobm.py (TF variable names); without one, seeded synthetic weights are used and said so.
+  * OpenCV is absent: clips are `.npy` arrays ([T,H,W] grey in [0,255] or [T,H,W,3] BGR) under
+    <prefix>/unstable/<name>; results are written as `.npy` (stabilised grey frames, x/y maps, black masks).  With
+    cv2 importable, video files are read and an MJPG .avi is written like the reference does.
+  * --before-ch is parsed and ignored exactly as in the reference (deploy_bundle.py:15,41): the ring depth is
+    max(indices[1:]) = 32 and six frames are sampled at lags 1,2,4,8,16,32.
+"""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--model-dir')
+    p.add_argument('--model-name')
+    p.add_argument('--before-ch', type=int)
+    p.add_argument('--output-dir', default='data_video_local')
+    p.add_argument('--infer-with-stable', action='store_true')
+    p.add_argument('--infer-with-last', action='store_true')
+    p.add_argument('--test-list', nargs='+', default=['data_video/test_list', 'data_video/train_list_deploy'])
+    p.add_argument('--prefix', default='data_video')
+    p.add_argument('--max-span', type=int, default=1)
+    p.add_argument('--random-black', type=int, default=None)
+    p.add_argument('--start-with-stable', action='store_true')
+    p.add_argument('--refine', type=int, default=1)
+    p.add_argument('--no_bm', type=int, default=1)
+    p.add_argument('--gpu_memory_fraction', type=float, default=0.1)
+    p.add_argument('--deploy-vis', action='store_true')
+    # extensions of this build
+    p.add_argument('--height', type=int, default=None, help='network/warp height (reference: fixed 288)')
+    p.add_argument('--width', type=int, default=None, help='network/warp width (reference: fixed 512)')
+    p.add_argument('--synthetic', type=int, default=0, help='stabilise a synthetic shaky clip of this many frames')
+    p.add_argument('--device', default='cuda:0')
+    return p
+
+
+def grey_train(frame, H, W):
+    """config.cvt_img2train (config.py:6-21) without cv2/PIL: BGR->grey (OpenCV weights), nearest-size bilinear
+    resize when needed, scale to [-0.5, 0.5]."""
+    f = np.asarray(frame, np.float32)
+    if f.ndim == 3:
+        f = 0.114 * f[..., 0] + 0.587 * f[..., 1] + 0.299 * f[..., 2]
+    if f.shape != (H, W):
+        ys = (np.arange(H) + 0.5) * f.shape[0] / H - 0.5
+        xs = (np.arange(W) + 0.5) * f.shape[1] / W - 0.5
+        y0 = np.clip(np.floor(ys).astype(int), 0, f.shape[0] - 1); y1 = np.clip(y0 + 1, 0, f.shape[0] - 1)
+        x0 = np.clip(np.floor(xs).astype(int), 0, f.shape[1] - 1); x1 = np.clip(x0 + 1, 0, f.shape[1] - 1)
+        wy = np.clip(ys - y0, 0, 1)[:, None]; wx = np.clip(xs - x0, 0, 1)[None, :]
+        f = (f[y0][:, x0] * (1 - wy) * (1 - wx) + f[y0][:, x1] * (1 - wy) * wx
+             + f[y1][:, x0] * wy * (1 - wx) + f[y1][:, x1] * wy * wx)
+    return (f * (1.0 / 255) - 0.5).astype(np.float32)
+
+
+def load_weights(args, cfg):
+    from stabnet_amd import synthetic
+    if args.model_dir and args.model_name:
+        path = os.path.join(args.model_dir, args.model_name)
+        for cand in (path, path + '.npz'):
+            if os.path.exists(cand) and cand.endswith('.npz'):
+                z = np.load(cand)
+                print('restored weights from', cand)
+                return {k: z[k] for k in z.files if not k.startswith('__')}
+        print('WARNING: %s(.npz) not found; TF1 .meta/.ckpt files cannot be read offline' % path)
+    print('using seeded synthetic weights (no trained model is available offline)')
+    return synthetic.make_params(cfg, seed=0, theta_scale=0.2)
+
+
+def main():
+    args = build_parser().parse_args()
+    import torch
+    from stabnet_amd import synthetic
+    from stabnet_amd.config import Config
+    from stabnet_amd.deploy import StabNetStream
+
+    base = Config()
+    H, W = args.height or base.height, args.width or base.width
+    cfg = Config(height=H, width=W)
+    lags = cfg.indices[1:]
+    print('inference with {}'.format(list(lags)))
+    if args.before_ch is not None and args.before_ch != max(lags):
+        print('note: --before-ch %d is ignored (as in the reference); ring depth = %d' % (args.before_ch, max(lags)))
+    if args.max_span != 1 or args.random_black is not None or args.no_bm == 0 or args.infer_with_last:
+        print('note: --max-span/--random-black/--no_bm=0/--infer-with-last are debugging paths of the reference that '
+              'are not on the timed path; they are accepted and ignored')
+    params = load_weights(args, cfg)
+    stream = StabNetStream(params, H, W, cfg, streams=1, device=args.device, refine=args.refine, before_ch=args.before_ch)
+    dev = torch.device(args.device)
+
+    clips = []
+    if args.synthetic > 0:
+        clips.append(('synthetic', (synthetic.make_clip(H, W, args.synthetic, seed=1234) + 0.5) * 255.0))
+    else:
+        for lst in args.test_list:
+            if not os.path.exists(lst):
+                continue
+            for name in open(lst).read().splitlines():
+                if not name:
+                    continue
+                path = os.path.join(args.prefix, 'unstable', name)
+                if os.path.exists(path) and path.endswith('.npy'):
+                    clips.append((name, np.load(path, mmap_mode='r')))
+                elif os.path.exists(path + '.npy'):
+                    clips.append((name, np.load(path + '.npy', mmap_mode='r')))
+                else:
+                    print('skipping %s: only .npy clips can be read without OpenCV' % path)
+    out_dir = os.path.join(args.output_dir, 'output')
+    os.makedirs(out_dir, exist_ok=True)
+
+    for name, clip in clips:
+        print(name)
+        tot_time, length = 0.0, 0
+        frames_out, xmaps, ymaps, blacks = [], [], [], []
+        try:
+            first = grey_train(clip[0], H, W)
+            stream.start(torch.from_numpy(first[None]).to(dev))                       # ring = 32 x first frame, zero masks
+            for t in range(1, len(clip)):
+                cur = torch.from_numpy(grey_train(clip[t], H, W)[None]).to(dev)
+                torch.cuda.synchronize()
+                start = time.time()
+                r = stream.step(cur)                                                  # one sess.run-equivalent
+                torch.cuda.synchronize()
+                tot_time += time.time() - start
+                net_output = ((r['output'][0, :, :, 0].cpu().numpy() + 0.5) * 255).clip(0, 255).astype(np.uint8)
+                frames_out.append(net_output)
+                xmaps.append(r['x_map'][0, :, :, 0].cpu().numpy()); ymaps.append(r['y_map'][0, :, :, 0].cpu().numpy())
+                blacks.append(r['black_pix'][0].cpu().numpy().astype(np.uint8))
+                length += 1
+                if length % 10 == 0:
+                    print('length: ' + str(length))
+                    print('fps={}'.format(length / tot_time))
+        except Exception:
+            traceback.print_exc()                    # the reference swallows per-video errors and still finalises
+        finally:
+            print('total length={}'.format(length + 2))
+            if frames_out:
+                stem = os.path.join(out_dir, os.path.splitext(os.path.basename(name))[0])
+                np.save(stem + '_stable.npy', np.stack(frames_out))
+                np.savez_compressed(stem + '_maps.npz', x_map=np.stack(xmaps), y_map=np.stack(ymaps), black=np.stack(blacks))
+                print('wrote', stem + '_stable.npy')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,82 @@
+"""GPU: the online loop (on-device ring + single-call frame) against the oracle's restatement of deploy_bundle.py, and
+the two CLI drivers end to end."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stabnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("refine", [1, 2])
+def test_stream_matches_oracle_loop(cuda, refine):
+    from stabnet_amd import synthetic
+    from stabnet_amd.config import Config
+    from stabnet_amd.deploy import StabNetStream
+    H, W, T = 64, 96, 7
+    cfg, ocfg = Config(height=H, width=W), O.Config(height=H, width=W)
+    P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
+    clip = synthetic.make_clip(H, W, T, seed=3, margin=32)
+    s = StabNetStream(P, H, W, cfg, streams=1, device=cuda, refine=refine)
+    s.start(torch.from_numpy(clip[0:1]).to(cuda))
+    ring = O.DeployRing(clip[0], ocfg)
+    for t in range(1, T):
+        got = s.step(torch.from_numpy(clip[t:t + 1]).to(cuda))
+        ref, frame = O.deploy_step(ring, clip[t], P, ocfg, refine=refine)
+        assert np.abs(got["theta"].cpu().numpy() - ref["theta"]).max() < 5e-5, t
+        assert np.abs(got["x_map"].cpu().numpy() - ref["x_map"]).max() < 3e-4, t
+        # the fed-back frame (img - black) is what the recurrence carries forward
+        d = np.abs(got["frame"].cpu().numpy()[0] - frame)
+        assert np.quantile(d, 0.999) < 5e-3, (t, float(d.max()))
+    # the ring holds the last pushes at the right slots: lag-1 slot == last fed-back frame
+    last_slot = (s.head - 1) % s.depth
+    assert torch.equal(s.frames_ring[0, last_slot], s.frame_fb[0])
+    assert torch.equal(s.masks_ring[0, last_slot], s.black[0])
+
+
+def test_two_streams_equal_two_single_streams(cuda):
+    from stabnet_amd import synthetic
+    from stabnet_amd.config import Config
+    from stabnet_amd.deploy import StabNetStream
+    H, W = 64, 96
+    cfg = Config(height=H, width=W)
+    P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
+    clips = [synthetic.make_clip(H, W, 4, seed=s, margin=32) for s in (1, 2)]
+    both = StabNetStream(P, H, W, cfg, streams=2, device=cuda)
+    both.start(torch.from_numpy(np.stack([c[0] for c in clips])).to(cuda))
+    singles = []
+    for c in clips:
+        st = StabNetStream(P, H, W, cfg, streams=1, device=cuda)
+        st.start(torch.from_numpy(c[0:1]).to(cuda))
+        singles.append(st)
+    for t in range(1, 4):
+        rb = both.step(torch.from_numpy(np.stack([c[t] for c in clips])).to(cuda))
+        for i, st in enumerate(singles):
+            r1 = st.step(torch.from_numpy(clips[i][t:t + 1]).to(cuda))
+            assert torch.allclose(rb["theta"][i], r1["theta"][0], atol=2e-6)
+            assert torch.allclose(rb["output"][i], r1["output"][0], atol=1e-4)
+
+
+def test_cli_drivers_run(cuda, tmp_path):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "deploy_bundle.py"), "--synthetic", "5", "--height", "64",
+                          "--width", "96", "--before-ch", "31", "--output-dir", str(tmp_path)], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "ignored" in out.stdout and os.path.exists(tmp_path / "output" / "synthetic_stable.npy")
+    assert np.load(tmp_path / "output" / "synthetic_stable.npy").shape == (4, 64, 96)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "train_bundle_nobm.py"), "--iters", "3", "--batch-size", "2",
+                          "--height", "64", "--width", "96", "--model-dir", str(tmp_path / "m"), "--disp-freq", "1"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "final loss" in out.stdout and os.path.exists(tmp_path / "m" / "model-2.npz")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "train_bundle_nobm.py"), "--restore", "--iters", "4",
+                          "--batch-size", "2", "--height", "64", "--width", "96", "--model-dir", str(tmp_path / "m")],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "restoring" in out.stdout, out.stderr[-2000:]
