@@ -167,7 +167,8 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof) {
         else if (t == T128x64) rc = launch_one<128, 64, 16, 64, 32>(a, st);
         else rc = launch_one<64, 64, 16, 32, 32>(a, st);
     }
-    if (rec) prof->end(st, PK_KERNEL_CONV_BASE + t * 2 + (bk32 ? 1 : 0), 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
+    const int mode = a.up > 1 ? 2 : (a.pad == 0 ? 0 : 1);
+    if (rec) prof->end(st, PK_KERNEL_CONV_BASE + mode * 6 + t * 2 + (bk32 ? 1 : 0), 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
                        4.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.K * a.Cout + (double)a.M * a.Cout * a.splitk),
                        a.M, a.Cout, a.K, a.splitk);
     if (rc) return rc;

@@ -439,12 +439,15 @@ const char* stabnet_prof_kind_name(int kind) {
         case PK_KERNEL_PUSH: return "ring_push_kernel";
         case PK_KERNEL_SPLITK_REDUCE: return "conv_splitk_reduce_kernel";
         case PK_KERNEL_WGRAD: return "conv_wgrad_f32_kernel";
-        case PK_KERNEL_CONV_BASE + 0: return "conv_igemm_f32_kernel<128,128,16,64,64>";
-        case PK_KERNEL_CONV_BASE + 1: return "conv_igemm_f32_kernel<128,128,32,64,64>";
-        case PK_KERNEL_CONV_BASE + 2: return "conv_igemm_f32_kernel<128,64,16,64,32>";
-        case PK_KERNEL_CONV_BASE + 3: return "conv_igemm_f32_kernel<128,64,32,64,32>";
-        case PK_KERNEL_CONV_BASE + 4: return "conv_igemm_f32_kernel<64,64,16,32,32>";
-        case PK_KERNEL_CONV_BASE + 5: return "conv_igemm_f32_kernel<64,64,32,32,32>";
+        default: break;
+    }
+    if (kind >= PK_KERNEL_CONV_BASE && kind < PK_KERNEL_CONV_BASE + 18) {
+        // names as rocprofv3 prints the template instantiation: <BM, BN, BK, WM, WN, MODE, NBUF>
+        static thread_local char buf[96];
+        const int k = kind - PK_KERNEL_CONV_BASE, mode = k / 6, t = (k % 6) / 2, bk = (k & 1) ? 32 : 16;
+        const int bm = (t == 2) ? 64 : 128, bn = (t == 0) ? 128 : 64, wm = (t == 2) ? 32 : 64, wn = (t == 0) ? 64 : 32;
+        snprintf(buf, sizeof(buf), "conv_igemm_f32_kernel<%d, %d, %d, %d, %d, %d, 2>", bm, bn, bk, wm, wn, mode);
+        return buf;
     }
     return "?";
 }
