@@ -7,7 +7,8 @@ int launch_max_pool(const float* x, float* y, int N, int H, int W, int C, int Ho
                     int pl, hipStream_t st);
 int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int G,
                    float* scale, float* shift, hipStream_t st);
+int gap_chunks(int HW);   // partial buffer = N * gap_chunks(HW) * C floats
 int launch_gap_bn_relu(const float* x, const float* scale, const float* shift, int N, int HW, int C, float* out,
-                       hipStream_t st);
+                       float* partial, hipStream_t st);
 int launch_fc(const float* x, const float* w, const float* b, float* y, int M, int K, int Nout, int relu,
               hipStream_t st);

@@ -6,6 +6,7 @@
 //   gap_bn_relu    : postnorm BN + ReLU + reduce_mean([1,2])                    s_net_bundle_nobm.py:254
 //   fc             : slim.fully_connected / output_layer for small batches      s_net_bundle_nobm.py:256-259, resnet.py:44-56
 #include "layers.h"
+#include <algorithm>
 
 __global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                            long npix, int C, int Cp) {
@@ -60,26 +61,44 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ 
     shift[i] = beta[i] - mean[i] * inv;
 }
 
-// out[n][c] = mean over (h,w) of relu(x*scale[c] + shift[c]).  block = 64 channels x 4 row groups; grid (C/64, N).
-__global__ __launch_bounds__(256) void gap_bn_relu_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, int HW, int C,
-                                                          float* __restrict__ out) {
-    __shared__ float part[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int g = threadIdx.x >> 6;
-    const int n = blockIdx.y;
-    float s = 0.f;
+// out[n][c] = mean over (h,w) of relu(x*scale[c] + shift[c]).  Two stages so that a single image still fills the chip:
+// stage 1: grid (C/64, chunks, N), block = 16 channel-quads x 16 row lanes, partial sums [N][chunks][C];
+// stage 2: fixed-order sum of the chunk partials (deterministic) and the division by H*W.
+__global__ __launch_bounds__(256) void gap_bn_relu_partial_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, int HW, int C,
+                                                                  int rows_per_chunk, float* __restrict__ partial) {
+    __shared__ float4 part[16][16];
+    const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + q * 4;
+    const int n = blockIdx.z;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(HW, r0 + rows_per_chunk);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < C) {
-        const float sc = scale[c], sh = shift[c];
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
         const float* p = x + (size_t)n * HW * C + c;
-        for (int i = g; i < HW; i += 4) s += fmaxf(p[(size_t)i * C] * sc + sh, 0.f);
+        for (int i = r0 + rl; i < r1; i += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)i * C);
+            s.x += fmaxf(v.x * sc.x + sh.x, 0.f); s.y += fmaxf(v.y * sc.y + sh.y, 0.f);
+            s.z += fmaxf(v.z * sc.z + sh.z, 0.f); s.w += fmaxf(v.w * sc.w + sh.w, 0.f);
+        }
     }
-    part[g][threadIdx.x & 63] = s;
+    part[rl][q] = s;
     __syncthreads();
-    if (g == 0 && c < C) {
-        const float t = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
-        out[(size_t)n * C + c] = t / (float)HW;
+    if (rl == 0 && c < C) {
+        float4 t = part[0][q];
+        for (int i = 1; i < 16; ++i) { const float4 u = part[i][q]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        *reinterpret_cast<float4*>(partial + ((size_t)n * gridDim.y + blockIdx.y) * C + c) = t;
     }
+}
+
+__global__ __launch_bounds__(256) void gap_finalize_kernel(const float* __restrict__ partial, int chunks, int HW, int C,
+                                                           float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (c >= C) return;
+    float t = 0.f;
+    for (int k = 0; k < chunks; ++k) t += partial[((size_t)n * chunks + k) * C + c];
+    out[(size_t)n * C + c] = t / (float)HW;
 }
 
 // y[m][n] = act( sum_k x[m][k] * W[n][k] + b[n] ), M <= 16 rows per pass.  One wave per output channel n:
@@ -141,11 +160,17 @@ int launch_bn_fold(const float* gamma, const float* beta, const float* mean, con
     return STABNET_OK;
 }
 
+int gap_chunks(int HW) { return std::max(1, std::min(32, HW / 32)); }
+
 int launch_gap_bn_relu(const float* x, const float* scale, const float* shift, int N, int HW, int C, float* out,
-                       hipStream_t st) {
-    SN_REQUIRE(N <= 65535, "gap: N too large");
-    gap_bn_relu_kernel<<<dim3(cdiv(C, 64), N), 256, 0, st>>>(x, scale, shift, HW, C, out);
-    SN_LAUNCH_CHECK("gap_bn_relu_kernel");
+                       float* partial, hipStream_t st) {
+    SN_REQUIRE(N <= 65535 && C % 4 == 0, "gap: bad shape");
+    const int chunks = gap_chunks(HW);
+    const int rpc = cdiv(HW, chunks);
+    gap_bn_relu_partial_kernel<<<dim3(cdiv(C, 64), chunks, N), 256, 0, st>>>(x, scale, shift, HW, C, rpc, partial);
+    SN_LAUNCH_CHECK("gap_bn_relu_partial_kernel");
+    gap_finalize_kernel<<<dim3(cdiv(C, 256), N), 256, 0, st>>>(partial, chunks, HW, C, out);
+    SN_LAUNCH_CHECK("gap_finalize_kernel");
     return STABNET_OK;
 }
 

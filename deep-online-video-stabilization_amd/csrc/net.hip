@@ -322,6 +322,7 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             net->params.push_back(e);
         }
     net->act_floats = ar.peak;
+    net->splitk_bytes = std::max(net->splitk_bytes, sizeof(float) * (size_t)N * gap_chunks(net->t_last.H * net->t_last.W) * net->t_last.C);
     net->max_net = std::max({net->max_net, net->t_c1.size, net->t_pool.size});
     return net;
 }
@@ -358,7 +359,7 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
                 break;
             case S_GAP:
                 rc = launch_gap_bn_relu(ws + s.in_off, scale + s.bn_off, shift + s.bn_off, s.N, s.H * s.W, s.C,
-                                        ws + s.out_off, st);
+                                        ws + s.out_off, splitk, st);          // partials live in the split-K scratch
                 break;
             case S_FC:
                 rc = launch_fc(ws + s.in_off, params + s.w_off, params + s.b_off,
@@ -431,7 +432,7 @@ const char* stabnet_prof_kind_name(int kind) {
     switch (kind) {
         case PK_KERNEL_PAD: return "pad_channels_kernel";
         case PK_KERNEL_POOL: return "max_pool_kernel";
-        case PK_KERNEL_GAP: return "gap_bn_relu_kernel";
+        case PK_KERNEL_GAP: return "gap_bn_relu_partial_kernel";
         case PK_KERNEL_FC: return "fc_kernel";
         case PK_KERNEL_MESH: return "mesh_homography_kernel";
         case PK_KERNEL_WARP: return "warp_sample_kernel";
@@ -705,7 +706,7 @@ static int run_forward_train(const Net* net, float* params, const float* x, floa
                 break;
             case S_GAP:
                 if ((rc = need_bn(s.bn_off)) != 0) return rc;
-                rc = launch_gap_bn_relu(ws + s.in_off, scale + s.bn_off, shift + s.bn_off, s.N, s.H * s.W, s.C, ws + s.out_off, st);
+                rc = launch_gap_bn_relu(ws + s.in_off, scale + s.bn_off, shift + s.bn_off, s.N, s.H * s.W, s.C, ws + s.out_off, splitk, st);
                 break;
             case S_FC:
                 rc = launch_fc(ws + s.in_off, params + s.w_off, params + s.b_off,
