@@ -71,35 +71,34 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
+static int g_force_tile = -2, g_force_split = -1;   // tuning hook (tools/autotune.py); -2 = read the environment once
+
 static int pick_tile(const ConvArgs& a, int& splitk) {
-    static const int force_tile = env_int("STABNET_CONV_TILE", -1);      // tuning overrides (not used by default)
-    static const int force_split = env_int("STABNET_CONV_SPLITK", -1);
+    if (g_force_tile == -2) {
+        g_force_tile = env_int("STABNET_CONV_TILE", -1);
+        g_force_split = env_int("STABNET_CONV_SPLITK", -1);
+    }
+    const int force_tile = g_force_tile, force_split = g_force_split;
     if (force_tile >= 0) {
         const int bk0 = (a.Cin % 32 == 0) ? 32 : 16;
         const int steps0 = a.KH * a.KW * (a.Cin / bk0);
         splitk = force_split > 0 ? std::min(force_split, steps0) : 1;
         return force_tile;
     }
+    // Measured rule (tools/autotune.py, profiles/r01_autotune_*.txt): at every shape of the regressor -- batch-1 720p,
+    // batch-8 288x512 forward and dgrad -- the 64x64 tile is the fastest (its 4 blocks/CU hide the per-wave load/LDS
+    // bubbles best); split-K pays only when the grid has fewer than ~400 blocks, with ~640/blocks slices of >= 8 K-steps.
     const int bk = (a.Cin % 32 == 0) ? 32 : 16;
     const int total_steps = a.KH * a.KW * (a.Cin / bk);
-    const int target = 512;                       // >= 2 blocks per CU over the 256 CUs
-    int best = T64x64;
-    for (int t = 0; t < 3; ++t) {
-        int bm, bn;
-        tile_dims(t, bm, bn);
-        if (bn > a.Cout && t != T64x64) continue;
-        const long blocks = (long)cdiv(a.M, bm) * cdiv(a.Cout, bn);
-        if (blocks >= target) { best = t; splitk = 1; return best; }
+    const long blocks = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64);
+    int s = 1;
+    if (blocks < 400 && a.Cout % 4 == 0) {
+        s = (int)((640 + blocks / 2) / blocks);
+        s = std::min(s, std::max(1, total_steps / 8));
+        s = std::min(s, 32);
     }
-    int bm, bn;
-    tile_dims(best, bm, bn);
-    const long blocks = (long)cdiv(a.M, bm) * cdiv(a.Cout, bn);
-    int s = (int)((target + blocks - 1) / blocks);
-    s = min(s, max(1, total_steps / 8));          // keep >= 8 K-steps per slice
-    s = min(s, 32);
-    if (a.Cout % 4 != 0) s = 1;
-    splitk = max(1, s);
-    return best;
+    splitk = std::max(1, s);
+    return T64x64;
 }
 
 size_t conv_plan(ConvArgs& a) {
@@ -208,6 +207,13 @@ static int fill_args(ConvArgs& a, const float* x, const float* w, const float* b
 }
 
 extern "C" {
+
+/* Tuning hook: force the tile (0 = 128x128, 1 = 128x64, 2 = 64x64) and split-K of every subsequent convolution;
+ * tile < 0 restores the built-in choice.  Not thread-safe; used by tools/autotune.py only. */
+void stabnet_conv_tuning_override(int tile, int splitk) {
+    g_force_tile = tile < 0 ? -1 : tile;
+    g_force_split = splitk;
+}
 
 size_t stabnet_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     ConvArgs a;

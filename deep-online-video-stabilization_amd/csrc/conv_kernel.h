@@ -3,6 +3,20 @@
 #include "conv.h"
 #include <climits>
 
+#ifdef CONV_STAMP                      // probe-only: s_memtime stamps per block (never defined in the library build)
+__device__ unsigned long long* g_conv_stamps;
+#define CONV_STAMP_AT(i)                                                                               \
+    do {                                                                                               \
+        if (threadIdx.x == 0) {                                                                        \
+            unsigned long long t_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+            g_conv_stamps[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))) * 4 + (i)] = t_; \
+        }                                                                                              \
+    } while (0)
+#else
+#define CONV_STAMP_AT(i)
+#endif
+
 #ifndef CONV_ABLATE
 #define CONV_ABLATE 0          // probe-only bit mask: 1 no global loads, 2 no LDS stores, 4 no epilogue stores, 8 no MFMA
 #endif
@@ -27,6 +41,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int STAGE = (BM + BN) * PITCH;
 
+    CONV_STAMP_AT(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -176,6 +191,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
         store_tiles(0);
     }
     __syncthreads();
+    CONV_STAMP_AT(1);
 
     const int frag_off = (lane & 31) * PITCH + (lane >> 5) * 4;
     for (int ks = ks_begin; ks < ks_end; ++ks) {
@@ -183,28 +199,45 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
         if (ks + 1 < ks_end) load_tiles();                // global loads in flight under the MFMAs
         const float* Ab = smem + buf * STAGE + (wm * WM) * PITCH + frag_off;
         const float* Bb = smem + buf * STAGE + (BM + wn * WN) * PITCH + frag_off;
+        // fragment reads run one kk ahead of the MFMAs that consume them (LDS latency hidden under the matrix work)
+        float4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * PITCH);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * PITCH);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            float4 af[TM], bf[TN];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * PITCH + kk * 8);
+                for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * PITCH + (kk + 1) * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * PITCH + kk * 8);
+                for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * PITCH + (kk + 1) * 8);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].x, bf[cur][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].y, bf[cur][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].z, bf[cur][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].w, bf[cur][j].w, acc[i][j], 0, 0, 0);
                 }
+        }
+        // pin the interleave: reads of kk+1 are issued BEFORE the MFMAs of kk (hipcc otherwise regroups them into
+        // "read 2 kk, wait, 8 MFMAs", exposing the LDS latency at one wave per SIMD)
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            if (kk + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
         }
         if (NBUF == 1) __syncthreads();                   // single LDS stage: everyone is done reading it
         if (ks + 1 < ks_end) store_tiles(NBUF == 2 ? (buf ^ 1) : 0);
         __syncthreads();
     }
 
+    CONV_STAMP_AT(2);
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool split = p.splitk > 1;
     float* const outp = split ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : p.y;
@@ -250,5 +283,6 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
             }
         }
     }
+    CONV_STAMP_AT(3);
 }
 

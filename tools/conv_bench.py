@@ -2,7 +2,7 @@
 """Single-convolution microbenchmark through the C ABI (for rocprofv3 / tile tuning).
   python tools_conv_bench.py N H W Cin Cout k stride pad [reps] [prologue]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stabnet_amd import ops
 a = [int(v) for v in sys.argv[1:9]]

@@ -2,7 +2,7 @@
 """Per-launch table of one deploy frame (kernel, GEMM shape, us, TFLOP/s, GB/s) from the in-library HIP-event profiler.
   python tools_layer_table.py [--height 720 --width 1280 --reps 20]"""
 import argparse, sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from stabnet_amd import synthetic
 from stabnet_amd.config import Config
