@@ -86,6 +86,7 @@ def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
            "tower_fwd_gflop": tr.plan.flops / 1e9, "loss": tr.losses()["total_loss"] if rank == 0 else None}
     if with_prof and rank == 0:
         prof = Profiler(max_records=4 * (steps // 2 + 1) * 600)
+        prof.calibrate()
         tr.prof = prof
         for _ in range(max(1, steps // 2)):
             tr.forward_backward(dev_b, gates)
@@ -94,6 +95,23 @@ def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
         out["roofline"] = roof
         out["kernels"] = table[:6]
     return out
+
+
+def pmc_traffic(kernel, workload_is_default):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate runs of this same command, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  Only valid for
+    the default 720p workload the passes were taken on; None otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_bench720p.json")
+    if not workload_is_default or not os.path.exists(path):
+        return None
+    try:
+        tab = json.load(open(path))
+    except Exception:
+        return None
+    for k, v in tab.items():
+        if k.replace("void ", "").split("(")[0] == kernel:
+            return v["hbm_bytes_per_launch_corrected"]
+    return None
 
 
 def roofline_from_records(recs, steps):
@@ -231,6 +249,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         # the same K steps again with an event pair around every launch (instrumentation kept out of `value`)
         prof = Profiler(max_records=args.steps * (stream.reg.plan.num_launches + 16))
+        event_overhead_ms = prof.calibrate()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
@@ -239,6 +258,8 @@ def main():
         torch.cuda.synchronize()
         prof_ms = 1e3 * (time.perf_counter() - t1) / args.steps
         roof, table = roofline_from_records(prof.records(), args.steps)
+        roof["traffic"] = pmc_traffic(roof["kernel"], (H, W, S, args.refine) == (720, 1280, 1, 1))
+        roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic_bench720p.json (rocprofv3 --pmc, separate passes)"
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -272,6 +293,7 @@ def main():
             line["roofline"] = roof
             line["kernels"] = table[:8]
             line["instrumented_ms_per_step"] = prof_ms
+            line["roofline"]["event_pair_overhead_us_subtracted"] = 1e3 * event_overhead_ms
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if train is not None:

@@ -408,6 +408,13 @@ int stabnet_prof_reset(void* pp) {
     static_cast<Prof*>(pp)->n = 0;
     return STABNET_OK;
 }
+/* Records one event pair with nothing between them on `stream` (kind 0): the per-pair overhead to subtract. */
+int stabnet_prof_record_empty(void* pp, void* stream) {
+    Prof* p = static_cast<Prof*>(pp);
+    SN_REQUIRE(p, "prof_record_empty: null");
+    if (p->begin((hipStream_t)stream)) p->end((hipStream_t)stream, 0, 0.0, 0.0);
+    return STABNET_OK;
+}
 int stabnet_prof_num_records(const void* pp) { return pp ? static_cast<const Prof*>(pp)->n : -1; }
 /* The stream the records were taken on must have been synchronised by the caller. */
 int stabnet_prof_record(const void* pp, int idx, int* kind, float* ms, double* flops, double* bytes) {
@@ -615,7 +622,7 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
 // train_bundle_nobm.py:155-160).  The plan must have been created with keep_activations = 1.
 // =========================================================================================================
 struct TrainLayout {
-    size_t bn_scale, bn_shift, bn_mean, bn_invstd, GA, GB, T1, T2, T3, fcg0, fcg1, partial, coef, wt, splitk, total;
+    size_t bn_scale, bn_shift, bn_mean, bn_invstd, GA, GB, T1, T2, T3, fcg0, fcg1, partial, coef, wt, argmax, splitk, total;
     size_t splitk_bytes;
 };
 
@@ -645,6 +652,7 @@ static TrainLayout train_layout(const Net* net) {
     L.partial = take(red);
     L.coef = take(3 * std::max<size_t>(net->max_c, 2048));
     L.wt = take(net->max_w);
+    L.argmax = take((net->t_pool.size + 3) / 4);              // one byte per pooled element
     size_t sk = net->splitk_bytes;
     for (const UnitInfo& u : net->units) {
         ConvArgs a3 = dgrad_args(u.r2.N, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0);
@@ -702,7 +710,8 @@ static int run_forward_train(const Net* net, float* params, const float* x, floa
                 break;
             }
             case S_POOL:
-                rc = launch_max_pool(ws + s.in_off, ws + s.out_off, s.N, s.H, s.W, s.C, s.Ho, s.Wo, s.k, s.stride, s.pt, s.pl, st);
+                rc = launch_max_pool_argmax(ws + s.in_off, ws + s.out_off, reinterpret_cast<unsigned char*>(ws + L.argmax), s.N,
+                                            s.H, s.W, s.C, s.Ho, s.Wo, s.k, s.stride, s.pt, s.pl, st);
                 break;
             case S_GAP:
                 if ((rc = need_bn(s.bn_off)) != 0) return rc;
@@ -795,7 +804,8 @@ static int run_backward(const Net* net, const float* params, const float* d_thet
     // ---- stem: max-pool backward, conv1 weight/bias gradient (the input needs no gradient)
     const TensorRef& c1 = net->t_c1;
     const TensorRef& pl = net->t_pool;
-    if ((rc = launch_max_pool_bwd(ws + c1.off, GA, GB, N, c1.H, c1.W, c1.C, pl.H, pl.W, 3, 2, net->pool_pt, net->pool_pl, st)) != 0) return rc;
+    if ((rc = launch_max_pool_bwd(reinterpret_cast<const unsigned char*>(ws + L.argmax), GA, GB, N, c1.H, c1.W, c1.C, pl.H, pl.W,
+                                  3, 2, net->pool_pt, net->pool_pl, st)) != 0) return rc;
     if ((rc = launch_bias_grad(GB, (long)N * c1.H * c1.W, 64, grads + net->b_stem, partial, st)) != 0) return rc;
     return wgrad_launch(ws + net->t_xin.off, GB, grads + net->w_stem, nullptr, nullptr, N, net->H, net->W, net->in_ch_pad, 64, 7,
                         7, 2, 3, st, prof);

@@ -12,8 +12,10 @@ int launch_bn_relu_bwd(const float* x, const float* g, const float* scale, const
                        const float* invstd, const float* gamma, long M, int C, const float* addend, int add_stride, int H,
                        int W, float* d_gamma, float* d_beta, float* d_x, float* partial, float* coef, hipStream_t st);
 int launch_bias_grad(const float* g, long M, int C, float* d_bias, float* partial, hipStream_t st);
-int launch_max_pool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo, int k,
-                        int stride, int pt, int pl, hipStream_t st);
+int launch_max_pool_bwd(const unsigned char* argmax, const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo,
+                        int k, int stride, int pt, int pl, hipStream_t st);
+int launch_max_pool_argmax(const float* x, float* y, unsigned char* argmax, int N, int H, int W, int C, int Ho, int Wo, int k,
+                           int stride, int pt, int pl, hipStream_t st);
 int launch_gap_bwd(const float* dg, int N, int HW, int C, float* da, hipStream_t st);
 int launch_fc_bwd(const float* x, const float* w, const float* y, const float* dy, int M, int K, int Nout, int relu,
                   float* dW, float* db, float* dx, hipStream_t st);

@@ -63,21 +63,37 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
     }
 }
 
+// Sum of the chunk partials for 64 channels per block: 4 lanes per channel walk the chunks (float64), fixed-order
+// combine through LDS (deterministic).  Returns the two sums in lane 0 of each channel.
+__device__ __forceinline__ void combine_partials(const float* __restrict__ partial, int chunks, int C, int c, int lane,
+                                                 double& s0, double& s1) {
+    __shared__ double sh0[4][64], sh1[4][64];
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C)
+        for (int k = lane; k < chunks; k += 4) {
+            a0 += (double)partial[(size_t)k * 2 * C + c];
+            a1 += (double)partial[(size_t)k * 2 * C + C + c];
+        }
+    sh0[lane][threadIdx.x & 63] = a0;
+    sh1[lane][threadIdx.x & 63] = a1;
+    __syncthreads();
+    const int t = threadIdx.x & 63;
+    s0 = ((sh0[0][t] + sh0[1][t]) + sh0[2][t]) + sh0[3][t];
+    s1 = ((sh1[0][t] + sh1[1][t]) + sh1[2][t]) + sh1[3][t];
+}
+
 // BN statistics finalize: batch mean / biased variance (float64 combine) -> folded (scale, shift), saved (mean, invstd),
-// moving averages.
+// moving averages.  grid = C/64 blocks of 256 threads.
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int chunks, long M, int C,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float eps, float decay, float* __restrict__ scale,
                                                                 float* __restrict__ shift, float* __restrict__ save_mean,
                                                                 float* __restrict__ save_invstd, float* __restrict__ mov_mean,
                                                                 float* __restrict__ mov_var) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-        s += (double)partial[(size_t)k * 2 * C + c];
-        ss += (double)partial[(size_t)k * 2 * C + C + c];
-    }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    double s, ss;
+    combine_partials(partial, chunks, C, c, lane, s, ss);
+    if (lane != 0 || c >= C) return;
     const double mean = s / (double)M;
     const double var = fmax(ss / (double)M - mean * mean, 0.0);
     const float meanf = (float)mean, varf = (float)var;
@@ -99,13 +115,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                               float* __restrict__ d_gamma, float* __restrict__ d_beta,
                                                               float* __restrict__ coef) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, sx = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-        s += (double)partial[(size_t)k * 2 * C + c];
-        sx += (double)partial[(size_t)k * 2 * C + C + c];
-    }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    double s, sx;
+    combine_partials(partial, chunks, C, c, lane, s, sx);
+    if (lane != 0 || c >= C) return;
     d_beta[c] += (float)s;
     d_gamma[c] += (float)sx;
     coef[c] = gamma[c] * invstd[c];
@@ -115,10 +128,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void bias_grad_finalize_kernel(const float* __restrict__ partial, int chunks, int C,
                                                                  float* __restrict__ d_bias) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int k = 0; k < chunks; ++k) s += (double)partial[(size_t)k * 2 * C + c];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    double s, unused;
+    combine_partials(partial, chunks, C, c, lane, s, unused);
+    if (lane != 0 || c >= C) return;
     d_bias[c] += (float)s;
 }
 
@@ -167,9 +180,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     *reinterpret_cast<float4*>(d_x + r * C + c) = o;
 }
 
-// max_pool2d backward, gather form (deterministic): an input pixel receives the gradient of every window whose first
-// maximum (scan order dy, dx) it is.
-__global__ __launch_bounds__(256) void max_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// max_pool2d backward, gather form (deterministic, no atomics): an input pixel receives the gradient of every window
+// whose argmax (saved by the training forward as dy*k+dx, first maximum in scan order) points at it.
+__global__ __launch_bounds__(256) void max_pool_bwd_kernel(const unsigned char* __restrict__ argmax, const float* __restrict__ dy,
                                                            float* __restrict__ dx, int N, int H, int W, int C, int Ho,
                                                            int Wo, int k, int stride, int pt, int pl) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
@@ -180,28 +193,44 @@ __global__ __launch_bounds__(256) void max_pool_bwd_kernel(const float* __restri
     const int ix = (int)(r % W); r /= W;
     const int iy = (int)(r % H);
     const int n = (int)(r / H);
-    const float v = x[q];
     float acc = 0.f;
     const int oy_lo = max(0, (iy + pt - k + stride) / stride), oy_hi = min(Ho - 1, (iy + pt) / stride);
     const int ox_lo = max(0, (ix + pl - k + stride) / stride), ox_hi = min(Wo - 1, (ix + pl) / stride);
     for (int oy = oy_lo; oy <= oy_hi; ++oy)
         for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-            // is (iy, ix) the first maximum of window (oy, ox)?
-            bool first_max = true;
-            for (int dyy = 0; dyy < k && first_max; ++dyy) {
-                const int yy = oy * stride - pt + dyy;
-                if (yy < 0 || yy >= H) continue;
-                for (int dxx = 0; dxx < k; ++dxx) {
-                    const int xx = ox * stride - pl + dxx;
-                    if (xx < 0 || xx >= W) continue;
-                    const float u = x[(((long)n * H + yy) * W + xx) * C + c];
-                    const bool before = (yy < iy) || (yy == iy && xx < ix);
-                    if (u > v || (u == v && before)) { first_max = false; break; }
-                }
-            }
-            if (first_max) acc += dy[(((long)n * Ho + oy) * Wo + ox) * C + c];
+            const long o = (((long)n * Ho + oy) * Wo + ox) * C + c;
+            const int am = argmax[o];
+            if (oy * stride - pt + am / k == iy && ox * stride - pl + am % k == ix) acc += dy[o];
         }
     dx[q] = acc;
+}
+
+// max_pool2d forward that also records the argmax (training).
+__global__ __launch_bounds__(256) void max_pool_argmax_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              unsigned char* __restrict__ argmax, int N, int H, int W, int C,
+                                                              int Ho, int Wo, int k, int stride, int pt, int pl) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)N * Ho * Wo * C;
+    if (q >= total) return;
+    const int c = (int)(q % C);
+    long r = q / C;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float m = -INFINITY;
+    int am = 0;
+    for (int dyy = 0; dyy < k; ++dyy) {
+        const int iy = oy * stride - pt + dyy;
+        if (iy < 0 || iy >= H) continue;
+        for (int dxx = 0; dxx < k; ++dxx) {
+            const int ix = ox * stride - pl + dxx;
+            if (ix < 0 || ix >= W) continue;
+            const float v = x[(((long)n * H + iy) * W + ix) * C + c];
+            if (v > m) { m = v; am = dyy * k + dxx; }
+        }
+    }
+    y[q] = m;
+    argmax[q] = (unsigned char)am;
 }
 
 // d a[n,hw,c] = d g[n,c] / HW   (reduce_mean backward; the BN+ReLU before it is handled by the BN backward kernels)
@@ -338,7 +367,7 @@ int launch_bn_stats(const float* x, long M, int C, const float* gamma, const flo
     const int chunks = reduce_chunks(M, rpc);
     col_reduce_kernel<0><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, rpc, partial);
     SN_LAUNCH_CHECK("col_reduce_kernel<0>");
-    bn_stats_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(partial, chunks, M, C, gamma, beta, eps, decay, scale, shift,
+    bn_stats_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(partial, chunks, M, C, gamma, beta, eps, decay, scale, shift,
                                                            save_mean, save_invstd, mov_mean, mov_var);
     SN_LAUNCH_CHECK("bn_stats_finalize_kernel");
     return STABNET_OK;
@@ -352,7 +381,7 @@ int launch_bn_relu_bwd(const float* x, const float* g, const float* scale, const
     const int chunks = reduce_chunks(M, rpc);
     col_reduce_kernel<1><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(x, g, scale, shift, mean, invstd, M, C, rpc, partial);
     SN_LAUNCH_CHECK("col_reduce_kernel<1>");
-    bn_bwd_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(partial, chunks, M, C, gamma, invstd, d_gamma, d_beta, coef);
+    bn_bwd_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(partial, chunks, M, C, gamma, invstd, d_gamma, d_beta, coef);
     SN_LAUNCH_CHECK("bn_bwd_finalize_kernel");
     bn_bwd_apply_kernel<<<cdiv(M * (C / 4), 256), 256, 0, st>>>(x, g, scale, shift, mean, invstd, coef, addend, add_stride, H,
                                                                 W, M, C, d_x);
@@ -366,15 +395,23 @@ int launch_bias_grad(const float* g, long M, int C, float* d_bias, float* partia
     const int chunks = reduce_chunks(M, rpc);
     col_reduce_kernel<2><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(nullptr, g, nullptr, nullptr, nullptr, nullptr, M, C, rpc, partial);
     SN_LAUNCH_CHECK("col_reduce_kernel<2>");
-    bias_grad_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(partial, chunks, C, d_bias);
+    bias_grad_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(partial, chunks, C, d_bias);
     SN_LAUNCH_CHECK("bias_grad_finalize_kernel");
     return STABNET_OK;
 }
 
-int launch_max_pool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo, int k,
-                        int stride, int pt, int pl, hipStream_t st) {
-    max_pool_bwd_kernel<<<cdiv((long)N * H * W * C, 256), 256, 0, st>>>(x, dy, dx, N, H, W, C, Ho, Wo, k, stride, pt, pl);
+int launch_max_pool_bwd(const unsigned char* argmax, const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo,
+                        int k, int stride, int pt, int pl, hipStream_t st) {
+    max_pool_bwd_kernel<<<cdiv((long)N * H * W * C, 256), 256, 0, st>>>(argmax, dy, dx, N, H, W, C, Ho, Wo, k, stride, pt, pl);
     SN_LAUNCH_CHECK("max_pool_bwd_kernel");
+    return STABNET_OK;
+}
+
+int launch_max_pool_argmax(const float* x, float* y, unsigned char* argmax, int N, int H, int W, int C, int Ho, int Wo, int k,
+                           int stride, int pt, int pl, hipStream_t st) {
+    SN_REQUIRE(k * k <= 255, "max_pool: window too large for the argmax byte");
+    max_pool_argmax_kernel<<<cdiv((long)N * Ho * Wo * C, 256), 256, 0, st>>>(x, y, argmax, N, H, W, C, Ho, Wo, k, stride, pt, pl);
+    SN_LAUNCH_CHECK("max_pool_argmax_kernel");
     return STABNET_OK;
 }
 

@@ -18,6 +18,7 @@ class Profiler:
 
     def __init__(self, max_records: int = 65536):
         self._h = ctypes.c_void_p()
+        self.overhead_ms = 0.0
         _lib.call("stabnet_prof_create", ctypes.byref(self._h), max_records)
 
     @property
@@ -26,6 +27,18 @@ class Profiler:
 
     def reset(self):
         _lib.call("stabnet_prof_reset", self._h)
+
+    def calibrate(self, n: int = 200) -> float:
+        """Median duration (ms) of an event pair with nothing between: hipEventRecord's own cost, to be subtracted
+        from every record so that per-launch times agree with rocprofv3's kernel durations."""
+        from ._tensor import stream_ptr
+        self.reset()
+        for _ in range(n):
+            _lib.call("stabnet_prof_record_empty", self._h, stream_ptr())
+        ms = sorted(r[1] for r in self.records())
+        self.reset()
+        self.overhead_ms = ms[len(ms) // 2]
+        return self.overhead_ms
 
     def records(self):
         """[(kernel name, ms, flops, bytes)] -- synchronises the device first."""
@@ -36,7 +49,8 @@ class Profiler:
         for i in range(L.stabnet_prof_num_records(self._h)):
             _lib.call("stabnet_prof_record", self._h, i, ctypes.byref(kind), ctypes.byref(ms), ctypes.byref(fl),
                       ctypes.byref(by))
-            out.append((L.stabnet_prof_kind_name(kind.value).decode(), ms.value, fl.value, by.value))
+            out.append((L.stabnet_prof_kind_name(kind.value).decode(), max(ms.value - self.overhead_ms, 0.0), fl.value,
+                        by.value))
         return out
 
     def records_with_shapes(self):

@@ -132,6 +132,7 @@ int stabnet_deploy_frame(const void* net, const float* params, const float* fold
 int stabnet_prof_create(void** prof, int max_records);
 void stabnet_prof_destroy(void* prof);
 int stabnet_prof_reset(void* prof);
+int stabnet_prof_record_empty(void* prof, void* stream);   /* an event pair around nothing: the overhead to subtract */
 int stabnet_prof_num_records(const void* prof);
 int stabnet_prof_record(const void* prof, int idx, int* kind, float* ms, double* flops, double* bytes);
 int stabnet_prof_record_shape(const void* prof, int idx, int* shape4);
