@@ -245,7 +245,7 @@ def main():
     checksum = float(stream.out_img.double().sum().item())
     plan_flops, plan_launches = stream.reg.plan.flops, stream.reg.plan.num_launches
 
-    roof, table, prof_ms = None, None, None
+    roof, table, prof_ms, roof_warp = None, None, None, None
     if rank == 0 and not args.no_roofline:
         # the same K steps again with an event pair around every launch (instrumentation kept out of `value`)
         prof = Profiler(max_records=args.steps * (stream.reg.plan.num_launches + 16))
@@ -258,6 +258,12 @@ def main():
         torch.cuda.synchronize()
         prof_ms = 1e3 * (time.perf_counter() - t1) / args.steps
         roof, table = roofline_from_records(prof.records(), args.steps)
+        for row in table:                      # the HBM-bound kernel of the path: the fused map + gather warp
+            if row["kernel"] == "warp_sample_kernel":
+                roof_warp = {"bound": "hbm", "kernel": "warp_sample_kernel<4>", "achieved": row["gbps"], "peak": PEAK_HBM_GBPS,
+                             "unit": "GB/s", "frac": row["gbps"] / PEAK_HBM_GBPS, "avg_launch_us": row["avg_us"],
+                             "algorithmic_bytes_per_launch": S * (20.0 * H * W + 776.0),
+                             "traffic": pmc_traffic("warp_sample_kernel<4>", (H, W, S, args.refine) == (720, 1280, 1, 1))}
         roof["traffic"] = pmc_traffic(roof["kernel"], (H, W, S, args.refine) == (720, 1280, 1, 1))
         roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic_bench720p.json (rocprofv3 --pmc, separate passes)"
 
@@ -291,6 +297,8 @@ def main():
         }
         if roof is not None:
             line["roofline"] = roof
+            if roof_warp is not None:
+                line["roofline_warp"] = roof_warp
             line["kernels"] = table[:8]
             line["instrumented_ms_per_step"] = prof_ms
             line["roofline"]["event_pair_overhead_us_subtracted"] = 1e3 * event_overhead_ms

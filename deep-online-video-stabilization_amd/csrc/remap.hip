@@ -1,0 +1,89 @@
+// Colour-frame remap with smoothed maps (deploy_bundle.py:136-146 warpRevBundle2), gfx950.
+// The reference does this on the host with OpenCV after every sess.run; here the maps never leave the device:
+//   map_shrink_kernel : cv2.resize(map, (W/rate, H/rate)) INTER_LINEAR (half-pixel centres, float32, h-pass then v-pass)
+//   remap_color_kernel: cv2.resize back to (W, H) fused with (m+1)/2*size and cv2.remap(..., INTER_LINEAR) on the uint8
+//                       BGR frame (coordinates quantised to 1/32 px like OpenCV, BORDER_CONSTANT 0)
+// Float32 op order as oracle/stabnet_oracle.py: cv_resize_linear_f32 / cv_remap_linear_u8 (-ffp-contract=off).  HBM-bound:
+// per frame 8*H*W (maps in) + 3*H*W (frame, gathered) + 3*H*W (out) bytes.
+#include "common.h"
+
+struct Taps1D { int i0, i1; float w0, w1; };
+
+__device__ __forceinline__ Taps1D cv_taps(int d, int n_src, double scale) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f = f - (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+    Taps1D t;
+    t.i0 = s; t.i1 = min(s + 1, n_src - 1); t.w0 = 1.0f - f; t.w1 = f;
+    return t;
+}
+
+__device__ __forceinline__ float cv_resize_at(const float* __restrict__ src, int sw, const Taps1D& tx, const Taps1D& ty) {
+    const float r0 = src[(size_t)ty.i0 * sw + tx.i0] * tx.w0 + src[(size_t)ty.i0 * sw + tx.i1] * tx.w1;
+    const float r1 = src[(size_t)ty.i1 * sw + tx.i0] * tx.w0 + src[(size_t)ty.i1 * sw + tx.i1] * tx.w1;
+    return r0 * ty.w0 + r1 * ty.w1;
+}
+
+// small[n][0|1][h][w] <- x_map, y_map shrunk.  One thread per low-resolution pixel.
+__global__ __launch_bounds__(256) void map_shrink_kernel(const float* __restrict__ x_map, const float* __restrict__ y_map, int H,
+                                                         int W, int h, int w, float* __restrict__ small_maps) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (q >= h * w) return;
+    const int dy = q / w, dx = q - dy * w;
+    const Taps1D tx = cv_taps(dx, W, (double)W / w), ty = cv_taps(dy, H, (double)H / h);
+    small_maps[((size_t)n * 2 + 0) * h * w + q] = cv_resize_at(x_map + (size_t)n * H * W, W, tx, ty);
+    small_maps[((size_t)n * 2 + 1) * h * w + q] = cv_resize_at(y_map + (size_t)n * H * W, W, tx, ty);
+}
+
+__global__ __launch_bounds__(256) void remap_color_kernel(const unsigned char* __restrict__ img, const float* __restrict__ small_maps,
+                                                          int H, int W, int C, int h, int w, unsigned char* __restrict__ out,
+                                                          float* __restrict__ px_out, float* __restrict__ py_out) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (q >= H * W) return;
+    const int y = q / W, x = q - y * W;
+    const Taps1D tx = cv_taps(x, w, (double)w / W), ty = cv_taps(y, h, (double)h / H);
+    const float xs = cv_resize_at(small_maps + ((size_t)n * 2 + 0) * h * w, w, tx, ty);
+    const float ys = cv_resize_at(small_maps + ((size_t)n * 2 + 1) * h * w, w, tx, ty);
+    const float px = (xs + 1.0f) / 2.0f * (float)W;                 // deploy_bundle.py:142-143
+    const float py = (ys + 1.0f) / 2.0f * (float)H;
+    if (px_out != nullptr) { px_out[(size_t)n * H * W + q] = px; py_out[(size_t)n * H * W + q] = py; }
+    const long sx = (long)rintf(px * 32.0f), sy = (long)rintf(py * 32.0f);      // cvRound: half to even
+    const long ix = sx >> 5, iy = sy >> 5;
+    const float fx = (float)(sx & 31) / 32.0f, fy = (float)(sy & 31) / 32.0f;
+    const float w00 = (1.0f - fx) * (1.0f - fy), w01 = fx * (1.0f - fy), w10 = (1.0f - fx) * fy, w11 = fx * fy;
+    const unsigned char* im = img + (size_t)n * H * W * C;
+    const bool x0 = ix >= 0 && ix < W, x1 = ix + 1 >= 0 && ix + 1 < W, y0 = iy >= 0 && iy < H, y1 = iy + 1 >= 0 && iy + 1 < H;
+    for (int c = 0; c < C; ++c) {
+        const float v00 = (x0 && y0) ? (float)im[((size_t)iy * W + ix) * C + c] : 0.f;
+        const float v01 = (x1 && y0) ? (float)im[((size_t)iy * W + ix + 1) * C + c] : 0.f;
+        const float v10 = (x0 && y1) ? (float)im[((size_t)(iy + 1) * W + ix) * C + c] : 0.f;
+        const float v11 = (x1 && y1) ? (float)im[((size_t)(iy + 1) * W + ix + 1) * C + c] : 0.f;
+        const float acc = ((v00 * w00 + v01 * w01) + v10 * w10) + v11 * w11;
+        out[((size_t)n * H * W + q) * C + c] = (unsigned char)fminf(fmaxf(rintf(acc), 0.f), 255.f);
+    }
+}
+
+extern "C" {
+
+/* warpRevBundle2(img, x_map, y_map) (deploy_bundle.py:136-146): img uint8 [N,H,W,C] (BGR, C = 3), x_map, y_map [N,H,W]
+ * normalised (the warp's outputs) -> out uint8 [N,H,W,C].  workspace: 2*N*(H/rate)*(W/rate) floats.  px_out/py_out
+ * (optional, [N,H,W]): the smoothed maps in pixel coordinates that cv2.remap would receive. */
+int stabnet_warp_rev_bundle2(const unsigned char* img, const float* x_map, const float* y_map, int N, int H, int W, int C,
+                             int rate, unsigned char* out, float* workspace, float* px_out, float* py_out, void* stream) {
+    SN_REQUIRE(img && x_map && y_map && out && workspace, "warp_rev_bundle2: null pointer");
+    SN_REQUIRE(N > 0 && N <= 65535 && C > 0 && rate >= 1 && H / rate >= 1 && W / rate >= 1, "warp_rev_bundle2: bad shape");
+    SN_REQUIRE((px_out == nullptr) == (py_out == nullptr), "warp_rev_bundle2: px_out and py_out go together");
+    const int h = H / rate, w = W / rate;
+    hipStream_t st = (hipStream_t)stream;
+    map_shrink_kernel<<<dim3(cdiv(h * w, 256), N), 256, 0, st>>>(x_map, y_map, H, W, h, w, workspace);
+    SN_LAUNCH_CHECK("map_shrink_kernel");
+    remap_color_kernel<<<dim3(cdiv((long)H * W, 256), N), 256, 0, st>>>(img, workspace, H, W, C, h, w, out, px_out, py_out);
+    SN_LAUNCH_CHECK("remap_color_kernel");
+    return STABNET_OK;
+}
+
+}  // extern "C"

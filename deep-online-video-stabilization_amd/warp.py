@@ -90,3 +90,25 @@ def interpolate(im: torch.Tensor, x: torch.Tensor, y: torch.Tensor, out_size=Non
     out = empty((N, H, W, C), im)
     _lib.call("stabnet_interp_fwd", ptr(im), ptr(x), ptr(y), N, H, W, C, ptr(out), stream_ptr())
     return out
+
+
+def warpRevBundle2(img: torch.Tensor, x_map: torch.Tensor, y_map: torch.Tensor, rate: int = 4, return_maps: bool = False):
+    """deploy_bundle.py:136-146 on the device.  img uint8 [N,H,W,3] (or [H,W,3]); x_map, y_map [N,H,W(,1)] normalised."""
+    squeeze = img.dim() == 3
+    if squeeze:
+        img = img[None]
+    if not img.is_cuda or img.dtype != torch.uint8:
+        raise _lib.StabnetError("warpRevBundle2: img must be a uint8 tensor on the GPU")
+    img = img.contiguous()
+    N, H, W, C = img.shape
+    xm = dev_f32(x_map, "x_map").reshape(N, H, W)
+    ym = dev_f32(y_map, "y_map").reshape(N, H, W)
+    out = torch.empty_like(img)
+    ws = torch.empty(2 * N * (H // rate) * (W // rate), dtype=torch.float32, device=img.device)
+    px = empty((N, H, W), xm) if return_maps else None
+    py = empty((N, H, W), xm) if return_maps else None
+    _lib.call("stabnet_warp_rev_bundle2", ptr(img), ptr(xm), ptr(ym), N, H, W, C, rate, ptr(out), ptr(ws), ptr(px), ptr(py),
+              stream_ptr())
+    if squeeze:
+        out = out[0]
+    return (out, px, py) if return_maps else out

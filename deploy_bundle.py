@@ -83,7 +83,7 @@ def load_weights(args, cfg):
 def main():
     args = build_parser().parse_args()
     import torch
-    from stabnet_amd import synthetic
+    from stabnet_amd import synthetic, warp
     from stabnet_amd.config import Config
     from stabnet_amd.deploy import StabNetStream
 
@@ -124,7 +124,7 @@ def main():
     for name, clip in clips:
         print(name)
         tot_time, length = 0.0, 0
-        frames_out, xmaps, ymaps, blacks = [], [], [], []
+        frames_out, xmaps, ymaps, blacks, colour_out = [], [], [], [], []
         try:
             first = grey_train(clip[0], H, W)
             stream.start(torch.from_numpy(first[None]).to(dev))                       # ring = 32 x first frame, zero masks
@@ -135,6 +135,10 @@ def main():
                 r = stream.step(cur)                                                  # one sess.run-equivalent
                 torch.cuda.synchronize()
                 tot_time += time.time() - start
+                if np.asarray(clip[t]).ndim == 3 and np.asarray(clip[t]).shape[:2] == (H, W):
+                    # warpRevBundle2 (deploy_bundle.py:136-146,303) on the device: colour frame remapped by the smoothed maps
+                    bgr = torch.from_numpy(np.ascontiguousarray(clip[t], dtype=np.uint8)).to(dev)
+                    colour_out.append(warp.warpRevBundle2(bgr, r['x_map'], r['y_map']).cpu().numpy())
                 net_output = ((r['output'][0, :, :, 0].cpu().numpy() + 0.5) * 255).clip(0, 255).astype(np.uint8)
                 frames_out.append(net_output)
                 xmaps.append(r['x_map'][0, :, :, 0].cpu().numpy()); ymaps.append(r['y_map'][0, :, :, 0].cpu().numpy())
@@ -150,6 +154,8 @@ def main():
             if frames_out:
                 stem = os.path.join(out_dir, os.path.splitext(os.path.basename(name))[0])
                 np.save(stem + '_stable.npy', np.stack(frames_out))
+                if colour_out:
+                    np.save(stem + '_stable_bgr.npy', np.stack(colour_out))
                 np.savez_compressed(stem + '_maps.npz', x_map=np.stack(xmaps), y_map=np.stack(ymaps), black=np.stack(blacks))
                 print('wrote', stem + '_stable.npy')
 

@@ -218,6 +218,13 @@ int stabnet_weight_decay(const float* params, float* grads, const long* seg_off,
 int stabnet_adam_step(float* params, const float* grads, const float* grads2, float* m, float* v, long n, float lr,
                       float beta1, float beta2, float eps, int step, float gscale, void* stream);
 
+/* ---- next to the path: colour-frame remap with smoothed maps --------------------------
+ * warpRevBundle2(img, x_map, y_map) (deploy_bundle.py:136-146,303): cv2.resize of both maps down by `rate` and back
+ * up (INTER_LINEAR), (m+1)/2*size, cv2.remap(img, ., ., INTER_LINEAR) of the uint8 BGR frame.  img, out uint8
+ * [N,H,W,C]; x_map, y_map [N,H,W]; workspace 2*N*(H/rate)*(W/rate) floats; px_out, py_out optional [N,H,W]. */
+int stabnet_warp_rev_bundle2(const unsigned char* img, const float* x_map, const float* y_map, int N, int H, int W, int C,
+                             int rate, unsigned char* out, float* workspace, float* px_out, float* py_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -641,3 +641,69 @@ def deploy_step(ring: DeployRing, cur, p, cfg: Config, refine=1):
         tmp[..., -1] = frame[None]
     ring.push(frame, black)
     return r, frame
+
+
+# --------------------------------------------------------------------------- colour remap (SURVEY 8f rank 1)
+def cv_resize_linear_f32(src, dw, dh):
+    """[external] cv2.resize(src, (dw, dh)) with the default INTER_LINEAR on a float32 single-channel image, restated
+    from OpenCV's published algorithm (resizeGeneric_/HResizeLinear/VResizeLinear): half-pixel centres
+    fx = (dx + 0.5) * scale - 0.5, source index clamped with the weight zeroed at the borders, horizontal pass then
+    vertical pass, float32 arithmetic.  (No INTER_AREA shortcut: that exists only for an exact 2x shrink.)"""
+    src = _f(src)
+    sh, sw = src.shape
+    sx_scale = float(sw) / dw
+    sy_scale = float(sh) / dh
+
+    def taps(n_dst, n_src, scale):
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(F)
+        s = np.floor(f).astype(np.int32)
+        f = f - s.astype(F)
+        lo = s < 0
+        f[lo] = 0
+        s[lo] = 0
+        hi = s >= n_src - 1
+        f[hi] = 0
+        s[hi] = n_src - 1
+        return s, np.minimum(s + 1, n_src - 1), (F(1.0) - f).astype(F), f.astype(F)
+
+    x0, x1, ax0, ax1 = taps(dw, sw, sx_scale)
+    y0, y1, by0, by1 = taps(dh, sh, sy_scale)
+    rows = src[:, x0] * ax0[None, :] + src[:, x1] * ax1[None, :]                  # horizontal pass on every source row
+    return rows[y0, :] * by0[:, None] + rows[y1, :] * by1[:, None]
+
+
+def cv_remap_linear_u8(img, map_x, map_y):
+    """[external] cv2.remap(img_u8, map_x, map_y, INTER_LINEAR), BORDER_CONSTANT 0, restated: coordinates are quantised
+    to 1/32 pixel (sx = cvRound(x*32), integer part sx >> 5, fraction (sx & 31)/32) as OpenCV does.  NOT reproduced:
+    OpenCV's 15-bit fixed-point weight table (its rounding differs from float weights by < 0.02 grey levels, so results
+    can differ by one grey level on exact .5 ties)."""
+    img = np.asarray(img, np.uint8)
+    H, W, C = img.shape
+    sx = np.rint(_f(map_x) * F(32)).astype(np.int64)
+    sy = np.rint(_f(map_y) * F(32)).astype(np.int64)
+    ix, iy = sx >> 5, sy >> 5
+    fx = ((sx & 31).astype(F)) / F(32)
+    fy = ((sy & 31).astype(F)) / F(32)
+
+    def tap(yy, xx):
+        ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+        v = img[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)].astype(F)
+        return np.where(ok[..., None], v, F(0))
+
+    w00 = ((F(1) - fx) * (F(1) - fy))[..., None]
+    w01 = (fx * (F(1) - fy))[..., None]
+    w10 = ((F(1) - fx) * fy)[..., None]
+    w11 = (fx * fy)[..., None]
+    acc = ((tap(iy, ix) * w00 + tap(iy, ix + 1) * w01) + tap(iy + 1, ix) * w10) + tap(iy + 1, ix + 1) * w11
+    return np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+
+
+def warpRevBundle2(img, x_map, y_map, rate=4):
+    """deploy_bundle.py:136-146: maps shrunk by `rate` and blown up again (seam smoothing), converted to pixel
+    coordinates (m + 1) / 2 * size, bilinear remap of the colour frame.  img [H,W,3] uint8; maps [H,W] normalised."""
+    H, W = x_map.shape
+    xs = cv_resize_linear_f32(cv_resize_linear_f32(x_map, int(W / rate), int(H / rate)), W, H)
+    ys = cv_resize_linear_f32(cv_resize_linear_f32(y_map, int(W / rate), int(H / rate)), W, H)
+    xs = (xs + F(1)) / F(2) * F(W)
+    ys = (ys + F(1)) / F(2) * F(H)
+    return cv_remap_linear_u8(img, xs, ys), xs, ys

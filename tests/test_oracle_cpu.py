@@ -176,3 +176,19 @@ def test_torch_gradient_oracle_agrees_with_numpy_forward():
     tn = O.temporal_loss(r1["output"], r1["black_pix"], r2["output"], r2["black_pix"], b["flow"], cfg)
     tt = T.temporal_loss(T.t(r1["output"]), T.t(r1["black_pix"]), T.t(r2["output"]), T.t(r2["black_pix"]), T.t(b["flow"]), cfg)
     assert abs(float(tt) - float(tn)) < 1e-4 * max(1.0, float(tn))
+
+
+def test_cv_restatement_known_answers():
+    """CPU KAT of the restatement: maps that address pixel centres exactly (x = j) return the frame itself."""
+    H, W = 16, 24
+    img = np.random.default_rng(0).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    mx = np.tile(np.arange(W, dtype=np.float32)[None], (H, 1))
+    my = np.tile(np.arange(H, dtype=np.float32)[:, None], (1, W))
+    assert np.array_equal(O.cv_remap_linear_u8(img, mx, my), img)
+    half = O.cv_remap_linear_u8(img, mx + 0.5, my)                       # half-pixel shift = mean of neighbours
+    want = np.rint((img[:, :-1].astype(np.float32) + img[:, 1:].astype(np.float32)) / 2)
+    assert np.array_equal(half[:, :-1], want.astype(np.uint8))
+    # resize: a constant map stays constant, a shrink by 4 of a ramp samples its centre of mass
+    assert np.all(O.cv_resize_linear_f32(np.full((8, 8), 3.0, np.float32), 2, 2) == 3.0)
+    ramp = np.tile(np.arange(8, dtype=np.float32)[None], (8, 1))
+    assert np.allclose(O.cv_resize_linear_f32(ramp, 2, 2)[0], [1.5, 5.5])

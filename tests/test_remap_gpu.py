@@ -1,0 +1,26 @@
+"""GPU: colour-frame remap with smoothed maps (deploy_bundle.py:136-146) vs the oracle's restatement of OpenCV's
+resize/remap geometry -- smoothed pixel-coordinate maps bit-exact, uint8 output exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stabnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("H,W", [(288, 512), (90, 130), (720, 1280)])
+def test_warp_rev_bundle2(cuda, H, W):
+    from stabnet_amd import warp
+    from stabnet_amd.config import Config
+    cfg, ocfg = Config(height=H, width=W), O.Config(height=H, width=W)
+    rng = np.random.default_rng(H)
+    theta = (rng.standard_normal((1, 50)) * 0.06).astype(np.float32)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    _, pts2 = O.get_4_pts(theta, ocfg)
+    x_map, y_map, _ = O.maps_from_Hs(O.get_Hs(pts2, ocfg), H, W, ocfg)
+    want, xs, ys = O.warpRevBundle2(img, x_map[0], y_map[0])
+    got, px, py = warp.warpRevBundle2(torch.from_numpy(img).to(cuda), torch.from_numpy(x_map).to(cuda),
+                                      torch.from_numpy(y_map).to(cuda), return_maps=True)
+    assert np.array_equal(px.cpu().numpy()[0], xs) and np.array_equal(py.cpu().numpy()[0], ys)
+    assert np.array_equal(got.cpu().numpy(), want)
