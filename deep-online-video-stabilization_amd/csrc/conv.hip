@@ -71,16 +71,20 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-static int g_force_tile = -2, g_force_split = -1;   // tuning hook (tools/autotune.py); -2 = read the environment once
+static int g_force_tile = -2, g_force_split = -1, g_force_bk16 = 0;
+
+static int conv_bk(const ConvArgs& a) { return (a.Cin % 32 == 0 && !g_force_bk16) ? 32 : 16; }
+   // tuning hook (tools/autotune.py); -2 = read the environment once
 
 static int pick_tile(const ConvArgs& a, int& splitk) {
     if (g_force_tile == -2) {
         g_force_tile = env_int("STABNET_CONV_TILE", -1);
         g_force_split = env_int("STABNET_CONV_SPLITK", -1);
+        g_force_bk16 = env_int("STABNET_CONV_BK16", 0);
     }
     const int force_tile = g_force_tile, force_split = g_force_split;
     if (force_tile >= 0) {
-        const int bk0 = (a.Cin % 32 == 0) ? 32 : 16;
+        const int bk0 = conv_bk(a);
         const int steps0 = a.KH * a.KW * (a.Cin / bk0);
         splitk = force_split > 0 ? std::min(force_split, steps0) : 1;
         return force_tile;
@@ -88,7 +92,7 @@ static int pick_tile(const ConvArgs& a, int& splitk) {
     // Measured rule (tools/autotune.py, profiles/r01_autotune_*.txt): at every shape of the regressor -- batch-1 720p,
     // batch-8 288x512 forward and dgrad -- the 64x64 tile is the fastest (its 4 blocks/CU hide the per-wave load/LDS
     // bubbles best); split-K pays only when the grid has fewer than ~400 blocks, with ~640/blocks slices of >= 8 K-steps.
-    const int bk = (a.Cin % 32 == 0) ? 32 : 16;
+    const int bk = conv_bk(a);
     const int total_steps = a.KH * a.KW * (a.Cin / bk);
     const long blocks = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64);
     int s = 1;
@@ -106,7 +110,7 @@ size_t conv_plan(ConvArgs& a) {
     a.K = a.KH * a.KW * a.Cin;
     int splitk = 1;
     (void)pick_tile(a, splitk);
-    const int bk = (a.Cin % 32 == 0) ? 32 : 16;
+    const int bk = conv_bk(a);
     const int total_steps = a.KH * a.KW * (a.Cin / bk);
     a.steps_per_split = cdiv(total_steps, splitk);
     a.splitk = cdiv(total_steps, a.steps_per_split);
@@ -154,7 +158,7 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof) {
     SN_REQUIRE(a.splitk == 1 || a.partial != nullptr, "conv: split-K needs a workspace");
     int splitk_unused = 1;
     const int t = pick_tile(a, splitk_unused);
-    const bool bk32 = (a.Cin % 32 == 0);
+    const bool bk32 = conv_bk(a) == 32;
     int rc;
     const bool rec = prof != nullptr && prof->begin(st);
     if (bk32) {

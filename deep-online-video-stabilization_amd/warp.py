@@ -112,3 +112,25 @@ def warpRevBundle2(img: torch.Tensor, x_map: torch.Tensor, y_map: torch.Tensor, 
     if squeeze:
         out = out[0]
     return (out, px, py) if return_maps else out
+
+
+def black_accumulate(black: torch.Tensor, all_black: torch.Tensor):
+    """all_black (int32, same numel) += round(black)   (deploy_bundle.py:291)."""
+    black = dev_f32(black, "black")
+    assert all_black.dtype == torch.int32 and all_black.is_cuda and all_black.numel() == black.numel()
+    _lib.call("stabnet_black_accumulate", ptr(black), ptr(all_black), black.numel(), stream_ptr())
+    return all_black
+
+
+def max_inscribed_rect(all_black: torch.Tensor, step: int = 10):
+    """deploy_bundle.py:344-366 on the device.  all_black int32 [H,W] -> ([i, j, hh, ww], area) as Python ints
+    (([], 0) when there is no free start pixel).  Synchronises (one 20-byte read-back per video)."""
+    assert all_black.dtype == torch.int32 and all_black.is_cuda and all_black.dim() == 2
+    all_black = all_black.contiguous()
+    H, W = all_black.shape
+    nbytes = _lib.lib().stabnet_crop_search_workspace_bytes(H, W, step)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=all_black.device)
+    ans = torch.empty(5, dtype=torch.int32, device=all_black.device)
+    _lib.call("stabnet_crop_search", ptr(all_black), H, W, step, ptr(ans), ptr(ws), ws.numel() * 8, stream_ptr())
+    a = ans.cpu().tolist()
+    return (a[:4], a[4]) if a[4] > 0 else ([], 0)

@@ -125,6 +125,7 @@ def main():
         print(name)
         tot_time, length = 0.0, 0
         frames_out, xmaps, ymaps, blacks, colour_out = [], [], [], [], []
+        all_black = torch.zeros((H, W), dtype=torch.int32, device=dev)           # deploy_bundle.py:234,291
         try:
             first = grey_train(clip[0], H, W)
             stream.start(torch.from_numpy(first[None]).to(dev))                       # ring = 32 x first frame, zero masks
@@ -135,6 +136,7 @@ def main():
                 r = stream.step(cur)                                                  # one sess.run-equivalent
                 torch.cuda.synchronize()
                 tot_time += time.time() - start
+                warp.black_accumulate(r['black_pix'][0], all_black)
                 if np.asarray(clip[t]).ndim == 3 and np.asarray(clip[t]).shape[:2] == (H, W):
                     # warpRevBundle2 (deploy_bundle.py:136-146,303) on the device: colour frame remapped by the smoothed maps
                     bgr = torch.from_numpy(np.ascontiguousarray(clip[t], dtype=np.uint8)).to(dev)
@@ -158,6 +160,12 @@ def main():
                     np.save(stem + '_stable_bgr.npy', np.stack(colour_out))
                 np.savez_compressed(stem + '_maps.npz', x_map=np.stack(xmaps), y_map=np.stack(ymaps), black=np.stack(blacks))
                 print('wrote', stem + '_stable.npy')
+                # max-inscribed black-free rectangle over the whole clip (deploy_bundle.py:344-371), searched on the device
+                ans, area = warp.max_inscribed_rect(all_black)
+                if ans:
+                    src = np.stack(colour_out) if colour_out else np.stack(frames_out)
+                    np.save(stem + '_cut.npy', src[:, ans[0]:ans[2] + 1, ans[1]:ans[3] + 1])
+                    print('crop', ans, 'area', area)
 
 
 if __name__ == '__main__':

@@ -225,6 +225,14 @@ int stabnet_adam_step(float* params, const float* grads, const float* grads2, fl
 int stabnet_warp_rev_bundle2(const unsigned char* img, const float* x_map, const float* y_map, int N, int H, int W, int C,
                              int rate, unsigned char* out, float* workspace, float* px_out, float* py_out, void* stream);
 
+/* ---- next to the path: max-inscribed-rectangle crop --------------------------------
+ * deploy_bundle.py:291: all_black += round(black) per frame;  :344-366: once per video, the largest black-free rectangle
+ * whose top-left corner lies on the `step` (10) grid of the top-left quadrant, first-found-wins on ties. */
+int stabnet_black_accumulate(const float* black, int* all_black, long n, void* stream);
+size_t stabnet_crop_search_workspace_bytes(int H, int W, int step);
+int stabnet_crop_search(const int* all_black, int H, int W, int step, int* ans5, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -707,3 +707,30 @@ def warpRevBundle2(img, x_map, y_map, rate=4):
     xs = (xs + F(1)) / F(2) * F(W)
     ys = (ys + F(1)) / F(2) * F(H)
     return cv_remap_linear_u8(img, xs, ys), xs, ys
+
+
+# --------------------------------------------------------------------------- crop search
+def max_inscribed_rect(all_black, step=10):
+    """deploy_bundle.py:344-366, literal restatement: largest black-free axis-aligned rectangle whose top-left corner
+    lies on the `step` grid of the top-left quadrant; the first rectangle (i, j, hh, ww ascending) of strictly larger
+    area wins.  all_black [H,W] integer counts.  Returns ([i, j, hh, ww], area); ([], 0) when no start pixel is free."""
+    all_black = np.asarray(all_black, np.int64)
+    H, W = all_black.shape
+    S = np.zeros((H + 1, W + 1), np.int64)
+    S[1:, 1:] = all_black.cumsum(0).cumsum(1)
+    max_s, ans = 0, []
+    for i in range(0, int(math.floor(H * 0.5)), step):
+        for j in range(0, int(math.floor(W * 0.5)), step):
+            if all_black[i, j] > 0:
+                continue
+            for hh in range(i, H):
+                # first column ww >= j at which rows i..hh contain black (the inner `break`), vectorised
+                row = S[hh + 1, j + 1:] - S[hh + 1, j] - S[i, j + 1:] + S[i, j]
+                bad = np.nonzero(row > 0)[0]
+                n_free = int(bad[0]) if bad.size else W - j
+                if n_free == 0:
+                    continue
+                s = (hh - i + 1) * n_free
+                if s > max_s:                   # within one hh the area grows with ww: the last free column is the max
+                    max_s, ans = s, [i, j, hh, j + n_free - 1]
+    return ans, max_s

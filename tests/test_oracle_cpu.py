@@ -192,3 +192,36 @@ def test_cv_restatement_known_answers():
     assert np.all(O.cv_resize_linear_f32(np.full((8, 8), 3.0, np.float32), 2, 2) == 3.0)
     ramp = np.tile(np.arange(8, dtype=np.float32)[None], (8, 1))
     assert np.allclose(O.cv_resize_linear_f32(ramp, 2, 2)[0], [1.5, 5.5])
+
+
+def test_crop_search_restatement_equals_the_literal_reference_loop():
+    """oracle.max_inscribed_rect vectorises the inner `ww` loop of deploy_bundle.py:344-366; check it against the literal
+    quadruple loop (incl. first-found-wins ties) on small masks."""
+    import math
+
+    def literal(all_black, step):
+        height, width = all_black.shape
+        black_sum = np.zeros([height + 1, width + 1], dtype=np.int64)
+        for i in range(height):
+            for j in range(width):
+                black_sum[i + 1][j + 1] = black_sum[i][j + 1] + black_sum[i + 1][j] - black_sum[i][j] + all_black[i][j]
+        max_s, ans = 0, []
+        for i in range(0, int(math.floor(height * 0.5)), step):
+            for j in range(0, int(math.floor(width * 0.5)), step):
+                if all_black[i][j] > 0:
+                    continue
+                for hh in range(i, height):
+                    for ww in range(j, width):
+                        if black_sum[hh + 1][ww + 1] - black_sum[hh + 1][j] - black_sum[i][ww + 1] + black_sum[i][j] > 0:
+                            break
+                        s = (hh - i + 1) * (ww - j + 1)
+                        if s > max_s:
+                            max_s, ans = s, [i, j, hh, ww]
+        return ans, max_s
+
+    rng = np.random.default_rng(1)
+    for t, dens in enumerate([0.0, 0.01, 0.03, 0.1, 0.3, 1.0]):
+        H, W = int(rng.integers(20, 44)), int(rng.integers(20, 50))
+        m = (rng.random((H, W)) < dens).astype(np.int64)
+        for step in (3, 10):
+            assert literal(m, step) == O.max_inscribed_rect(m, step), (t, step)
