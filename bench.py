@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--train-width", type=int, default=512)
     ap.add_argument("--train-steps", type=int, default=10, help="steps of the extra train leg of the default run")
     ap.add_argument("--no-train-leg", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the frame eagerly instead of replaying a hipGraph")
     return ap.parse_args()
 
 
@@ -224,7 +225,8 @@ def main():
     clip = synthetic.make_clip(H, W, args.clip_frames, seed=1234 + rank)
     clip_dev = torch.from_numpy(clip).to(dev)                      # resident in HBM before timing
     frames = [clip_dev[t:t + 1].expand(S, H, W).contiguous() for t in range(args.clip_frames)]
-    stream = StabNetStream(P, H, W, cfg, streams=S, device=dev, refine=args.refine, before_ch=args.before_ch)
+    stream = StabNetStream(P, H, W, cfg, streams=S, device=dev, refine=args.refine, before_ch=args.before_ch,
+                           use_graph=not args.no_graph)
     stream.start(frames[0])
 
     def barrier():
@@ -251,6 +253,7 @@ def main():
     barrier()
     checksum = float(stream.out_img.double().sum().item())
     plan_flops, plan_launches = stream.reg.plan.flops, stream.reg.plan.num_launches
+    graph_used = stream._graph is not None
 
     roof, table, prof_ms, roof_warp = None, None, None, None
     if rank == 0 and not args.no_roofline:
@@ -299,7 +302,7 @@ def main():
                                    "independent stream set per GPU (replicas only)" % (W, H, S, args.before_ch),
                        "height": H, "width": W, "streams_per_gpu": S, "refine": args.refine,
                        "backbone_gflop_per_frame": plan_flops / 1e9 / S,
-                       "launches_per_frame": plan_launches + 4},
+                       "launches_per_frame": plan_launches + 5, "hip_graph": bool(graph_used)},
             "per_gpu_fps": fps / world, "checksum": checksum,
         }
         if roof is not None:

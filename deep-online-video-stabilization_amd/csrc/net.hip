@@ -553,16 +553,18 @@ int stabnet_ring_init(float* frames_ring, float* masks_ring, const float* first_
 
 /* One iteration of the online loop for S = net.N independent streams (deploy_bundle.py:259-296,319-332):
  * stack assembly from the ring -> regressor -> get_4_pts + transformer -> frame = img - black -> push.
- * `head` = ring slot this frame's push writes (caller advances it: head = (head+1) % depth).  `lags` is a HOST array. */
+ * `head` (DEVICE int) = ring slot this frame's push writes; the call advances it, (head+1) % depth, with a one-thread
+ * kernel at the end, so the whole frame has fixed arguments and can be captured once into a hipGraph and replayed.
+ * `lags` is a HOST array (read at enqueue time). */
 int stabnet_deploy_frame(const void* netp, const float* params, const float* fold, float* frames_ring,
-                         float* masks_ring, int depth, int head, const int* lags, int n_lags, const float* cur_frame,
+                         float* masks_ring, int depth, int* head, const int* lags, int n_lags, const float* cur_frame,
                          int refine, int grid_h, int grid_w, float do_crop_rate, float* theta, float* out_img,
                          float* black, float* x_map, float* y_map, float* Hs, float* frame_fb, void* workspace,
                          size_t workspace_bytes, void* stream, void* profp) {
     const Net* net = static_cast<const Net*>(netp);
     SN_REQUIRE(net && params && fold && frames_ring && masks_ring && lags && cur_frame && theta && out_img && black &&
                    x_map && y_map && Hs && frame_fb && workspace, "deploy_frame: null pointer");
-    SN_REQUIRE(depth > 0 && head >= 0 && head < depth && refine >= 1, "deploy_frame: bad ring arguments");
+    SN_REQUIRE(depth > 0 && head != nullptr && refine >= 1, "deploy_frame: bad ring arguments");
     SN_REQUIRE(2 * n_lags + 1 == net->in_ch && n_lags <= 7, "deploy_frame: %d lags do not make %d channels", n_lags,
                net->in_ch);
     SN_REQUIRE((grid_h + 1) * (grid_w + 1) * 2 == net->n_theta, "deploy_frame: grid does not match n_theta");
@@ -606,12 +608,12 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
         if (last)
             rc = launch_ring_push(frames_ring, masks_ring, net->N, depth, head, out_img, black, hw, frame_fb, st);
         else
-            rc = launch_ring_push(frame_fb, nullptr, net->N, 1, 0, out_img, black, hw, nullptr, st);
+            rc = launch_ring_push(frame_fb, nullptr, net->N, 1, nullptr, out_img, black, hw, nullptr, st);
         if (rec) prof->end(st, PK_KERNEL_PUSH, 0, 4.0 * net->N * hw * 4);
         if (rc) return rc;
         if (!last) cur = frame_fb;
     }
-    return STABNET_OK;
+    return launch_ring_advance(head, depth, st);
 }
 
 }  // extern "C"

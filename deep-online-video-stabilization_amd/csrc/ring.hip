@@ -20,12 +20,14 @@ __global__ __launch_bounds__(256) void ring_init_kernel(float* __restrict__ fram
 // out[s][pix][c]: c in [0,n) masks at lags, [n,2n) frames at lags, 2n current frame, rest zero (channel padding).
 __global__ __launch_bounds__(256) void stack_assemble_kernel(const float* __restrict__ frames,
                                                              const float* __restrict__ masks,
-                                                             const float* __restrict__ cur, int depth, int head,
+                                                             const float* __restrict__ cur, int depth,
+                                                             const int* __restrict__ head_ptr,
                                                              const RingLags lags, long hw, int Cp,
                                                              float* __restrict__ out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const int s = blockIdx.y;
     if (i >= hw) return;
+    const int head = *head_ptr;
     float v[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) v[c] = 0.f;
@@ -53,12 +55,13 @@ __global__ __launch_bounds__(256) void stack_assemble_kernel(const float* __rest
 
 // frame = img + black * (-1) (:293); push frame and black into slot `head` (:322-323).
 __global__ __launch_bounds__(256) void ring_push_kernel(float* __restrict__ frames, float* __restrict__ masks, int depth,
-                                                        int head, const float* __restrict__ img,
+                                                        const int* __restrict__ head_ptr, const float* __restrict__ img,
                                                         const float* __restrict__ black, long hw,
                                                         float* __restrict__ frame_out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const int s = blockIdx.y;
     if (i >= hw) return;
+    const int head = (head_ptr != nullptr) ? *head_ptr : 0;
     const float b = black[(long)s * hw + i];
     const float f = img[(long)s * hw + i] + b * -1.0f;
     frames[((long)s * depth + head) * hw + i] = f;
@@ -72,7 +75,7 @@ int launch_ring_init(float* frames, float* masks, const float* first, int S, int
     return STABNET_OK;
 }
 
-int launch_stack_assemble(const float* frames, const float* masks, const float* cur, int S, int depth, int head,
+int launch_stack_assemble(const float* frames, const float* masks, const float* cur, int S, int depth, const int* head,
                           const RingLags& lags, long hw, int Cp, float* out, hipStream_t st) {
     SN_REQUIRE(lags.n >= 1 && lags.n <= 7 && 2 * lags.n + 1 <= Cp && Cp <= 16, "stack_assemble: %d lags do not fit %d channels",
                lags.n, Cp);
@@ -81,7 +84,15 @@ int launch_stack_assemble(const float* frames, const float* masks, const float* 
     return STABNET_OK;
 }
 
-int launch_ring_push(float* frames, float* masks, int S, int depth, int head, const float* img, const float* black,
+__global__ void ring_advance_kernel(int* head, int depth) { *head = (*head + 1) % depth; }
+
+int launch_ring_advance(int* head, int depth, hipStream_t st) {
+    ring_advance_kernel<<<1, 1, 0, st>>>(head, depth);
+    SN_LAUNCH_CHECK("ring_advance_kernel");
+    return STABNET_OK;
+}
+
+int launch_ring_push(float* frames, float* masks, int S, int depth, const int* head, const float* img, const float* black,
                      long hw, float* frame_out, hipStream_t st) {
     ring_push_kernel<<<dim3(cdiv(hw, 256), S), 256, 0, st>>>(frames, masks, depth, head, img, black, hw, frame_out);
     SN_LAUNCH_CHECK("ring_push_kernel");

@@ -80,7 +80,7 @@ class StabNetStream:
     ring depth is max(indices[1:])."""
 
     def __init__(self, params, H: int, W: int, cfg: Config = v2_93, streams: int = 1, device="cuda:0", refine: int = 1,
-                 before_ch=None):
+                 before_ch=None, use_graph: bool = False):
         self.cfg, self.H, self.W, self.S, self.refine = cfg, H, W, streams, refine
         self.reg = Regressor(params, streams, H, W, cfg, device)
         dev = self.reg.device
@@ -97,26 +97,53 @@ class StabNetStream:
         self.y_map = f(streams, H, W, 1)
         self.Hs = f(streams, cfg.grid_h, cfg.grid_w, 9)
         self.frame_fb = f(streams, H, W)
-        self.head = 0
+        self.cur = f(streams, H, W)                       # fixed-address staging buffer of the current frame
+        self.head_dev = torch.zeros(1, dtype=torch.int32, device=dev)     # ring head lives on the device (graph replay)
+        self.use_graph = use_graph
+        self._graph = None
         self.started = False
+
+    @property
+    def head(self) -> int:
+        """Ring slot the NEXT frame's push writes (host read-back; synchronises)."""
+        return int(self.head_dev.item())
 
     def start(self, first_frame: torch.Tensor):
         first = dev_f32(first_frame, "first_frame").reshape(self.S, self.H, self.W)
         _lib.call("stabnet_ring_init", ptr(self.frames_ring), ptr(self.masks_ring), ptr(first), self.S, self.depth,
                   self.H, self.W, stream_ptr())
-        self.head = 0
+        self.head_dev.zero_()
         self.started = True
+
+    def _enqueue(self, prof=None):
+        r = self.reg
+        _lib.call("stabnet_deploy_frame", r.plan.handle, ptr(r.params), ptr(r.fold), ptr(self.frames_ring),
+                  ptr(self.masks_ring), self.depth, ptr(self.head_dev), self._lags_c, len(self.lags), ptr(self.cur),
+                  self.refine, self.cfg.grid_h, self.cfg.grid_w, self.cfg.do_crop_rate, ptr(self.theta), ptr(self.out_img),
+                  ptr(self.black), ptr(self.x_map), ptr(self.y_map), ptr(self.Hs), ptr(self.frame_fb),
+                  ptr(r.workspace), r.workspace.numel(), stream_ptr(), prof.handle if prof is not None else 0)
 
     def step(self, cur: torch.Tensor, prof: Profiler = None):
         if not self.started:
             raise _lib.StabnetError("StabNetStream.step before start(first_frame)")
-        cur = dev_f32(cur, "cur").reshape(self.S, self.H, self.W)
-        r = self.reg
-        _lib.call("stabnet_deploy_frame", r.plan.handle, ptr(r.params), ptr(r.fold), ptr(self.frames_ring),
-                  ptr(self.masks_ring), self.depth, self.head, self._lags_c, len(self.lags), ptr(cur), self.refine,
-                  self.cfg.grid_h, self.cfg.grid_w, self.cfg.do_crop_rate, ptr(self.theta), ptr(self.out_img),
-                  ptr(self.black), ptr(self.x_map), ptr(self.y_map), ptr(self.Hs), ptr(self.frame_fb),
-                  ptr(r.workspace), r.workspace.numel(), stream_ptr(), prof.handle if prof is not None else 0)
-        self.head = (self.head + 1) % self.depth
+        self.cur.copy_(dev_f32(cur, "cur").reshape(self.S, self.H, self.W))            # D2D into the fixed buffer
+        if self.use_graph and prof is None:
+            if self._graph is None:
+                # one frame = ~95 launches with fixed arguments: capture once, replay per frame (hipGraph)
+                self._enqueue()                  # this frame runs eagerly (also loads modules / sets kernel attributes)
+                torch.cuda.synchronize()
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):        # capture records only; nothing executes here
+                        self._enqueue()
+                    self._graph = g
+                except Exception as e:               # capture unsupported on this runtime: stay eager, say so once
+                    import sys
+                    print("StabNetStream: hipGraph capture failed (%s); continuing without a graph" % e, file=sys.stderr)
+                    self.use_graph = False
+            else:
+                self._graph.replay()
+        else:
+            self._enqueue(prof)
         return {"output": self.out_img, "black_pix": self.black, "Hs": self.Hs, "x_map": self.x_map,
                 "y_map": self.y_map, "theta": self.theta, "frame": self.frame_fb}

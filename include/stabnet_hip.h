@@ -118,10 +118,12 @@ int stabnet_ring_init(float* frames_ring, float* masks_ring, const float* first_
  * the feedback after it:  13-channel stack from the ring at the dilated `lags` (HOST int array, e.g. 1,2,4,8,16,32;
  * channel order masks, frames, current) -> regressor -> get_4_pts -> transformer -> frame = img - black ->
  * frames_ring[head] = frame, masks_ring[head] = black.  refine > 1 repeats the network on the refined frame
- * (:284-295).  The caller advances head = (head + 1) % depth after the call.
+ * (:284-295).  `head` is a DEVICE int (ring slot of this frame's push); the call advances it to (head+1) % depth with
+ * a one-thread kernel, so every argument is fixed across frames and the call can be captured into a hipGraph once and
+ * replayed (copy the new frame into the fixed `cur_frame` buffer before each replay).
  * Outputs: theta [S,n_theta]; out_img, black, x_map, y_map, frame_fb [S,H,W]; Hs [S,gh,gw,9]. */
 int stabnet_deploy_frame(const void* net, const float* params, const float* fold, float* frames_ring,
-                         float* masks_ring, int depth, int head, const int* lags, int n_lags, const float* cur_frame,
+                         float* masks_ring, int depth, int* head, const int* lags, int n_lags, const float* cur_frame,
                          int refine, int grid_h, int grid_w, float do_crop_rate, float* theta, float* out_img,
                          float* black, float* x_map, float* y_map, float* Hs, float* frame_fb, void* workspace,
                          size_t workspace_bytes, void* stream, void* prof);

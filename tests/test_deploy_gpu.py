@@ -40,6 +40,26 @@ def test_stream_matches_oracle_loop(cuda, refine):
     assert torch.equal(s.masks_ring[0, last_slot], s.black[0])
 
 
+def test_graph_replay_equals_eager(cuda):
+    """The frame captured once into a hipGraph (device-side ring head) and replayed gives the eager results bit for bit."""
+    from stabnet_amd import synthetic
+    from stabnet_amd.config import Config
+    from stabnet_amd.deploy import StabNetStream
+    H, W, T = 64, 96, 40                          # > 32 frames: the ring wraps
+    cfg = Config(height=H, width=W)
+    P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
+    clip = torch.from_numpy(synthetic.make_clip(H, W, T, seed=4, margin=32)).to(cuda)
+    eager = StabNetStream(P, H, W, cfg, device=cuda, use_graph=False)
+    graph = StabNetStream(P, H, W, cfg, device=cuda, use_graph=True)
+    eager.start(clip[0:1]); graph.start(clip[0:1])
+    for t in range(1, T):
+        a = eager.step(clip[t:t + 1])
+        b = graph.step(clip[t:t + 1])
+        assert torch.equal(a["theta"], b["theta"]) and torch.equal(a["output"], b["output"]), t
+    assert graph._graph is not None and graph.head == eager.head == (T - 1) % 32
+    assert torch.equal(eager.frames_ring, graph.frames_ring) and torch.equal(eager.masks_ring, graph.masks_ring)
+
+
 def test_two_streams_equal_two_single_streams(cuda):
     from stabnet_amd import synthetic
     from stabnet_amd.config import Config
