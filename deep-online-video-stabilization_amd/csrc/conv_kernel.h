@@ -99,25 +99,32 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
     const float* const shp = has_pro ? p.in_shift : p.x;
     const unsigned s_voff = has_pro ? (unsigned)(lc4 * 4) : 0u;
 
-    // K-iteration state (wave-uniform): tap (kh,kw) and channel offset c0 of the NEXT tile to load
-    int l_kh, l_kw, l_c0;
+    // K-iteration state (wave-uniform) of the NEXT tile to load.  For MODE 0/1 the operand pointers are RUNNING pointers:
+    // consecutive K-steps are contiguous in memory for the weights (K index = (kh,kw,c)) and, inside one kernel row, for
+    // the activations too ((kh*W + kw)*Cin + c), so both advance by BK per step; only a kh wrap needs a jump.
+    int l_kh, l_kw, l_c0, l_tap;
     {
-        const int tap = ks_begin / cin_steps;
-        l_c0 = (ks_begin - tap * cin_steps) * BK;
-        l_kh = tap / p.KW;
-        l_kw = tap - l_kh * p.KW;
+        l_tap = ks_begin / cin_steps;
+        l_c0 = (ks_begin - l_tap * cin_steps) * BK;
+        l_kh = l_tap / p.KW;
+        l_kw = l_tap - l_kh * p.KW;
     }
+    const float* xb = p.x + ((l_kh * p.W + l_kw) * p.Cin + l_c0 - pad_off);       // uniform; may point before p.x
+    const float* wb = p.w + (l_tap * p.Cin + l_c0);
+    const float* scb = scp + (has_pro ? l_c0 : 0) + s_voff;                         // per-lane, advances uniformly
+    const float* shb = shp + (has_pro ? l_c0 : 0) + s_voff;
+    const int row_jump = (p.W - p.KW) * p.Cin;
 
     // Loads are unconditional (out-of-frame taps read a safe in-buffer address and are zeroed when the tile is written
     // to LDS) and the BN+ReLU prologue runs at LDS-store time, AFTER the MFMAs of the current step: nothing between the
     // global loads and the matrix work consumes the loaded registers, so the loads stay in flight under the MFMAs.
     float4 ra[A_PASSES], rb[B_PASSES], sc, sh;
-    unsigned okmask = 0;
+    bool okv[A_PASSES];                                   // lane masks (SGPR pairs), reused at LDS-store time
+#pragma unroll
+    for (int ps = 0; ps < A_PASSES; ++ps) okv[ps] = true;
     auto load_tiles = [&]() {
-        const int kh = l_kh, kw = l_kw, c0 = l_c0;
-        const int tap = kh * p.KW + kw;
-        okmask = 0;
         if (MODE == 2) {
+            const int kh = l_kh, kw = l_kw, c0 = l_c0;
 #pragma unroll
             for (int ps = 0; ps < A_PASSES; ++ps) {
                 int iy = a_iy0[ps] + kh, ix = a_ix0[ps] + kw;
@@ -127,31 +134,34 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
                 ok = ok & (iy < p.H) & (ix < p.W);
                 const unsigned off = a_voff[ps] + (unsigned)((iy * p.W + ix) * p.Cin + c0);
                 if (!(CONV_ABLATE & 1)) ra[ps] = *reinterpret_cast<const float4*>(p.x + (ok ? off : (unsigned)(lc4 * 4)));
-                okmask |= (ok ? 1u : 0u) << ps;
+                okv[ps] = ok;
             }
         } else {
-            const float* xb = p.x + ((kh * p.W + kw) * p.Cin + c0 - pad_off);     // uniform; may point before p.x
 #pragma unroll
             for (int ps = 0; ps < A_PASSES; ++ps) {
                 unsigned voff = a_voff[ps];
                 if (MODE == 1) {
-                    const bool ok = (a_mask[ps] >> tap) & 1ull;
-                    voff = ok ? voff : safe_voff;
-                    okmask |= (ok ? 1u : 0u) << ps;
+                    okv[ps] = (a_mask[ps] >> l_tap) & 1ull;
+                    voff = okv[ps] ? voff : safe_voff;
                 }
                 if (!(CONV_ABLATE & 1)) ra[ps] = *reinterpret_cast<const float4*>(xb + voff);
             }
         }
-        const float* wb = p.w + (tap * p.Cin + c0);                                 // uniform
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps)
             if (!(CONV_ABLATE & 1)) rb[ps] = *reinterpret_cast<const float4*>(wb + w_voff[ps]);
-        sc = *reinterpret_cast<const float4*>(scp + (has_pro ? c0 : 0) + s_voff);
-        sh = *reinterpret_cast<const float4*>(shp + (has_pro ? c0 : 0) + s_voff);
+        sc = *reinterpret_cast<const float4*>(scb);
+        sh = *reinterpret_cast<const float4*>(shb);
+        // advance to the next K-step
+        xb += BK;
+        wb += BK;
         l_c0 += BK;
+        if (has_pro) { scb += BK; shb += BK; }
         if (l_c0 == p.Cin) {
             l_c0 = 0;
-            if (++l_kw == p.KW) { l_kw = 0; ++l_kh; }
+            ++l_tap;
+            if (has_pro) { scb -= p.Cin; shb -= p.Cin; }
+            if (++l_kw == p.KW) { l_kw = 0; ++l_kh; xb += row_jump; }
         }
     };
     auto store_tiles = [&](int buf) {
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
                 v.z = fmaxf(__builtin_fmaf(v.z, sc.z, sh.z), 0.f);
                 v.w = fmaxf(__builtin_fmaf(v.w, sc.w, sh.w), 0.f);
             }
-            if (MODE != 0 && !((okmask >> ps) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE != 0 && !okv[ps]) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!(CONV_ABLATE & 2)) *reinterpret_cast<float4*>(As + (lrow + ps * ROWS_PER_PASS) * PITCH + lc4 * 4) = v;
             else asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
         }
