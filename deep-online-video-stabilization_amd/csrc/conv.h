@@ -11,6 +11,8 @@ struct ConvArgs {
     const float* in_scale;   // [Cin] or null: A-operand prologue  a = relu(a*scale + shift)  (folded BN + ReLU)
     const float* in_shift;   // [Cin]
     const float* residual;   // NHWC [N,res_H,res_W,Cout] or null; read at (oy*res_stride, ox*res_stride)
+    const float* out_scale;  // [Cout] or null: epilogue  y = y*out_scale + out_shift  (folded BN of the CONSUMER, inference)
+    const float* out_shift;
     float* partial;          // split-K workspace [splitk][M][Cout] (only when splitk > 1)
     // geometry
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;

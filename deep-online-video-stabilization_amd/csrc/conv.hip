@@ -20,6 +20,7 @@
 #include <algorithm>
 
 #include "conv_kernel.h"
+#include "conv_ring_kernel.h"
 
 // Sums the split-K partial slabs in a fixed order and applies the epilogue.  One thread per 4 channels.
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs p) {
@@ -51,6 +52,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
         }
         const float4 t = *reinterpret_cast<const float4*>(p.residual + ri);
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    if (p.out_scale != nullptr) {
+        const float4 a = *reinterpret_cast<const float4*>(p.out_scale + n), b = *reinterpret_cast<const float4*>(p.out_shift + n);
+        s.x = __builtin_fmaf(s.x, a.x, b.x); s.y = __builtin_fmaf(s.y, a.y, b.y);
+        s.z = __builtin_fmaf(s.z, a.z, b.z); s.w = __builtin_fmaf(s.w, a.w, b.w);
     }
     if (p.relu_out) {
         s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
@@ -152,6 +158,29 @@ static int launch_one(const ConvArgs& a, hipStream_t st) {
     return launch_one_t<BM, BN, BK, WM, WN, 1>(a, st);
 }
 
+// LDS-DMA ring kernel (conv_ring_kernel.h): no A-operand prologue, stride-free addressing, Cin % 32 == 0, 64x64 tile.
+static int g_ring = -1, g_ring_ns = 3;
+
+static bool ring_eligible(const ConvArgs& a, int tile) {
+    if (g_ring < 0) {
+        g_ring = env_int("STABNET_CONV_RING", 1);
+        g_ring_ns = env_int("STABNET_CONV_RING_NS", 3);
+    }
+    return g_ring && tile == T64x64 && a.in_scale == nullptr && a.up == 1 && a.Cin % 32 == 0 && !g_force_bk16;
+}
+
+template <int MODE, int NS>
+static int launch_ring_ns(const ConvArgs& a, hipStream_t st) {
+    dim3 grid(cdiv(a.M, 64), cdiv(a.Cout, 64), a.splitk);
+    conv_ring_f32_kernel<MODE, NS><<<grid, 256, 0, st>>>(a);
+    SN_LAUNCH_CHECK("conv_ring_f32_kernel");
+    return STABNET_OK;
+}
+
+static int launch_ring(const ConvArgs& a, hipStream_t st) {
+    return a.pad == 0 ? launch_ring_ns<0, 3>(a, st) : launch_ring_ns<1, 3>(a, st);
+}
+
 int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof) {
     SN_REQUIRE(a.Cin % 16 == 0, "conv: Cin=%d must be a multiple of 16 (pad the channels)", a.Cin);
     SN_REQUIRE(a.splitk >= 1 && a.steps_per_split >= 1, "conv: conv_plan() not called");
@@ -161,7 +190,10 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof) {
     const bool bk32 = conv_bk(a) == 32;
     int rc;
     const bool rec = prof != nullptr && prof->begin(st);
-    if (bk32) {
+    const bool ring = ring_eligible(a, t);
+    if (ring) {
+        rc = launch_ring(a, st);
+    } else if (bk32) {
         if (t == T128x128) rc = launch_one<128, 128, 32, 64, 64>(a, st);
         else if (t == T128x64) rc = launch_one<128, 64, 32, 64, 32>(a, st);
         else rc = launch_one<64, 64, 32, 32, 32>(a, st);
@@ -171,7 +203,7 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof) {
         else rc = launch_one<64, 64, 16, 32, 32>(a, st);
     }
     const int mode = a.up > 1 ? 2 : (a.pad == 0 ? 0 : 1);
-    if (rec) prof->end(st, PK_KERNEL_CONV_BASE + mode * 6 + t * 2 + (bk32 ? 1 : 0), 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
+    if (rec) prof->end(st, ring ? PK_KERNEL_CONV_RING + mode : PK_KERNEL_CONV_BASE + mode * 6 + t * 2 + (bk32 ? 1 : 0), 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
                        4.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.K * a.Cout + (double)a.M * a.Cout * a.splitk),
                        a.M, a.Cout, a.K, a.splitk);
     if (rc) return rc;
@@ -227,11 +259,27 @@ size_t stabnet_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, in
     return conv_plan(a);
 }
 
+int stabnet_conv2d_fwd_ex(const float* x, const float* w_ohwi, const float* bias, const float* in_scale,
+                          const float* in_shift, const float* residual, int res_H, int res_W, int res_stride,
+                          const float* out_scale, const float* out_shift, float* y, int N, int H, int W, int Cin,
+                          int Cout, int KH, int KW, int stride, int pad, int relu_out, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 int stabnet_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, const float* in_scale,
                        const float* in_shift, const float* residual, int res_H, int res_W, int res_stride, float* y,
                        int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu_out,
                        void* workspace, size_t workspace_bytes, void* stream) {
+    return stabnet_conv2d_fwd_ex(x, w_ohwi, bias, in_scale, in_shift, residual, res_H, res_W, res_stride, nullptr, nullptr,
+                                 y, N, H, W, Cin, Cout, KH, KW, stride, pad, relu_out, workspace, workspace_bytes, stream);
+}
+
+int stabnet_conv2d_fwd_ex(const float* x, const float* w_ohwi, const float* bias, const float* in_scale,
+                          const float* in_shift, const float* residual, int res_H, int res_W, int res_stride,
+                          const float* out_scale, const float* out_shift, float* y, int N, int H, int W, int Cin,
+                          int Cout, int KH, int KW, int stride, int pad, int relu_out, void* workspace,
+                          size_t workspace_bytes, void* stream) {
     SN_REQUIRE(x && w_ohwi && y, "conv2d_fwd: null pointer");
+    SN_REQUIRE((out_scale == nullptr) == (out_shift == nullptr), "conv2d_fwd: out_scale and out_shift go together");
     ConvArgs a;
     int rc = fill_args(a, x, w_ohwi, bias, in_scale, in_shift, residual, res_H, res_W, res_stride, y, N, H, W, Cin, Cout,
                        KH, KW, stride, pad, relu_out);
@@ -242,6 +290,8 @@ int stabnet_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, c
         return STABNET_ERR_WORKSPACE;
     }
     a.partial = static_cast<float*>(workspace);
+    a.out_scale = out_scale;
+    a.out_shift = out_shift;
     return conv_launch(a, (hipStream_t)stream);
 }
 

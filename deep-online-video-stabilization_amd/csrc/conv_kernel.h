@@ -23,6 +23,59 @@ __device__ unsigned long long* g_conv_stamps;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Epilogue shared by the convolution kernels.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// y = acc + bias (+ residual) ; y = y*out_scale + out_shift (optional) ; relu (optional); split-K slices store raw partials.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& p, int mw0, int nw0, int lane) {
+    const bool split = p.splitk > 1;
+    float* const outp = split ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : p.y;
+    const bool has_res = !split && p.residual != nullptr;
+    const bool has_obn = !split && p.out_scale != nullptr;
+    const bool res_plain = p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mrow0 = mw0 + i * 32 + 4 * (lane >> 5);
+        int roff[16];                                     // residual element offset of each accumulator row
+        if (has_res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = min(mrow0 + (r & 3) + 8 * (r >> 2), p.M - 1);
+                if (res_plain) {
+                    roff[r] = m * p.Cout;
+                } else {
+                    const int img = m / (p.Ho * p.Wo);
+                    const int rr = m - img * (p.Ho * p.Wo);
+                    const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
+                    roff[r] = ((img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.Cout;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nw0 + j * 32 + (lane & 31);
+            const bool ncol = n < p.Cout;
+            const int nc = min(n, p.Cout - 1);
+            const float bv = (!split && p.bias != nullptr) ? p.bias[nc] : 0.f;
+            const float os = has_obn ? p.out_scale[nc] : 1.f, ob = has_obn ? p.out_shift[nc] : 0.f;
+            float rv[16];
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = p.residual[(unsigned)(roff[r] + nc)];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] + bv;
+                if (has_res) v += rv[r];
+                if (has_obn) v = __builtin_fmaf(v, os, ob);
+                if (!split && p.relu_out) v = fmaxf(v, 0.f);
+                if (!(CONV_ABLATE & 4)) { if (ncol && m < p.M) outp[(size_t)m * p.Cout + n] = v; }
+                else if (v == 123.456f) outp[0] = v;
+            }
+        }
+    }
+}
+
 // MODE 0: no padding and no dilation (1x1 convs, any stride): every tap of every row < M is in frame -> no masks.
 // MODE 1: zero padding: a per-row bit mask (one bit per filter tap, built once) says which taps are in frame.
 // MODE 2: dilated input (dgrad of a strided conv): validity and address are recomputed per tap (slow path).
@@ -248,51 +301,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
     }
 
     CONV_STAMP_AT(2);
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool split = p.splitk > 1;
-    float* const outp = split ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : p.y;
-    const bool has_res = !split && p.residual != nullptr;
-    const bool res_plain = p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int mrow0 = m0 + wm * WM + i * 32 + 4 * (lane >> 5);
-        int roff[16];                                     // residual element offset of each accumulator row
-        if (has_res) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = min(mrow0 + (r & 3) + 8 * (r >> 2), p.M - 1);
-                if (res_plain) {
-                    roff[r] = m * p.Cout;
-                } else {
-                    const int img = m / (p.Ho * p.Wo);
-                    const int rr = m - img * (p.Ho * p.Wo);
-                    const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
-                    roff[r] = ((img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.Cout;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 32 + (lane & 31);
-            const bool ncol = n < p.Cout;
-            const int nc = min(n, p.Cout - 1);
-            const float bv = (!split && p.bias != nullptr) ? p.bias[nc] : 0.f;
-            float rv[16];
-            if (has_res) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rv[r] = p.residual[(unsigned)(roff[r] + nc)];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-                float v = acc[i][j][r] + bv;
-                if (has_res) v += rv[r];
-                if (!split && p.relu_out) v = fmaxf(v, 0.f);
-                if (!(CONV_ABLATE & 4)) { if (ncol && m < p.M) outp[(size_t)m * p.Cout + n] = v; }
-                else if (v == 123.456f) outp[0] = v;
-            }
-        }
-    }
+    conv_epilogue<TM, TN>(acc, p, m0 + wm * WM, n0 + wn * WN, lane);
     CONV_STAMP_AT(3);
 }
 

@@ -37,6 +37,8 @@ struct Step {
     int kind;
     ConvArgs conv;
     long in_off, out_off, res_off, w_off, b_off, bn_off;
+    long obn_off;                                // inference only: folded BN + ReLU of the CONSUMER fused behind this conv
+    int inf_preactivated;                        // inference only: the input tensor already holds relu(bn(.)) -> no prologue
     int N, H, W, C, Ho, Wo, k, stride, pt, pl;   // pool / pad / gap
     int M, K, Nout, relu;                        // fc
     size_t splitk_bytes;
@@ -164,6 +166,7 @@ static Step conv_step(Net& net, const TensorRef& in, const TensorRef& out, int K
     net.splitk_bytes = std::max(net.splitk_bytes, s.splitk_bytes);
     s.in_off = in.off; s.out_off = out.off; s.res_off = res ? res->off : NONE;
     s.w_off = w_off; s.b_off = b_off; s.bn_off = bn_off;
+    s.obn_off = NONE; s.inf_preactivated = 0;
     net.flops += 2.0 * a.M * (double)(a.KH * a.KW * (real_cin ? real_cin : a.Cin)) * a.Cout;   // algorithmic (un-padded)
     return s;
 }
@@ -238,6 +241,7 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
                 net->steps.push_back(conv_step(*net, cur, r1, 1, 1, 0, w, NONE, bn_pre, nullptr, 1));
                 ui.w1 = w;
             }
+            const size_t i_conv1 = net->steps.size() - 1;
             const long bn1 = net->add_bn(S + "conv1/BatchNorm", b.dbn);
             net->bns.push_back({bn1, b.dbn, r1.off, (long)N * r1.H * r1.W, r1.H, r1.W});
             TensorRef r2 = new_tensor(ar, N, Ho, Wo, b.dbn);
@@ -247,7 +251,15 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
                 ui.w2 = w;
             }
             done(r1);
+            const size_t i_conv2 = net->steps.size() - 1;
             const long bn2 = net->add_bn(S + "conv2/BatchNorm", b.dbn);
+            // Inference plan: conv1 and conv2 apply their consumer's folded BN + ReLU in the epilogue, so conv2 and conv3
+            // read activated tensors and run prologue-free (LDS-DMA ring kernel).  Same arithmetic per element
+            // (fma + max), applied once per activation instead of once per use.  Training keeps the raw conv outputs
+            // (the batch statistics are taken over them).
+            net->steps[i_conv1].obn_off = bn1;
+            net->steps[i_conv2].obn_off = bn2;
+            net->steps[i_conv2].inf_preactivated = 1;
             net->bns.push_back({bn2, b.dbn, r2.off, (long)N * r2.H * r2.W, r2.H, r2.W});
             TensorRef nxt = new_tensor(ar, N, Ho, Wo, b.depth);
             {
@@ -255,6 +267,7 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
                 const long bb = (long)net->add_param(S + "conv3/biases", PK_BIAS, b.depth, 0, 0, 0, 0);
                 // identity shortcut of a strided unit = subsample(x, stride): read the residual at (oy*s, ox*s)
                 net->steps.push_back(conv_step(*net, r2, nxt, 1, 1, 0, w, bb, bn2, &sc, own_sc ? 1 : stride));
+                net->steps.back().inf_preactivated = 1;
                 ui.w3 = w; ui.b3 = bb;
             }
             ui.sc = sc; ui.r1 = r1; ui.r2 = r2; ui.out = nxt; ui.proj = own_sc; ui.bn1 = bn1; ui.bn2 = bn2;
@@ -347,8 +360,14 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
                 a.w = params + s.w_off;
                 a.bias = s.b_off >= 0 ? params + s.b_off : nullptr;
                 a.residual = s.res_off >= 0 ? ws + s.res_off : nullptr;
-                a.in_scale = s.bn_off >= 0 ? scale + s.bn_off : nullptr;
-                a.in_shift = s.bn_off >= 0 ? shift + s.bn_off : nullptr;
+                const bool prologue = s.bn_off >= 0 && !s.inf_preactivated;
+                a.in_scale = prologue ? scale + s.bn_off : nullptr;
+                a.in_shift = prologue ? shift + s.bn_off : nullptr;
+                if (s.obn_off >= 0) {
+                    a.out_scale = scale + s.obn_off;
+                    a.out_shift = shift + s.obn_off;
+                    a.relu_out = 1;
+                }
                 a.partial = splitk;
                 rc = conv_launch(a, st, prof);
                 break;
@@ -449,6 +468,8 @@ const char* stabnet_prof_kind_name(int kind) {
         case PK_KERNEL_WGRAD: return "conv_wgrad_f32_kernel";
         default: break;
     }
+    if (kind == PK_KERNEL_CONV_RING) return "conv_ring_f32_kernel<0, 3>";
+    if (kind == PK_KERNEL_CONV_RING + 1) return "conv_ring_f32_kernel<1, 3>";
     if (kind >= PK_KERNEL_CONV_BASE && kind < PK_KERNEL_CONV_BASE + 18) {
         // names as rocprofv3 prints the template instantiation: <BM, BN, BK, WM, WN, MODE, NBUF>
         static thread_local char buf[96];

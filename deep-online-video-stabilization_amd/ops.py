@@ -23,7 +23,7 @@ def unpack_conv_weight(w_ohwi, cin: int) -> np.ndarray:
 
 
 def conv2d(x, w_ohwi, bias=None, in_scale=None, in_shift=None, residual=None, res_stride=1, stride=1, pad=0,
-           relu_out=False):
+           relu_out=False, out_scale=None, out_shift=None):
     x = dev_f32(x, "x")
     w = dev_f32(w_ohwi, "w")
     N, H, W, Cin = x.shape
@@ -36,9 +36,9 @@ def conv2d(x, w_ohwi, bias=None, in_scale=None, in_shift=None, residual=None, re
     ws_bytes = L.stabnet_conv2d_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
     ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=x.device)
     rH, rW = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)
-    _lib.call("stabnet_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(residual), rH, rW,
-              res_stride, ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, int(relu_out), ptr(ws), ws_bytes,
-              stream_ptr())
+    _lib.call("stabnet_conv2d_fwd_ex", ptr(x), ptr(w), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(residual), rH, rW,
+              res_stride, ptr(out_scale), ptr(out_shift), ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad,
+              int(relu_out), ptr(ws), ws_bytes, stream_ptr())
     return y
 
 

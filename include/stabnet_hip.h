@@ -73,6 +73,14 @@ int stabnet_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, c
                        const float* in_shift, const float* residual, int res_H, int res_W, int res_stride, float* y,
                        int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu_out,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* Same, with the NEXT layer's folded batch_norm fused behind the sum: y = act((conv + bias + residual)*out_scale[n] +
+ * out_shift[n]) (both or neither; NULL = plain epilogue).  This is how the inference plan runs the
+ * conv1 -> bn -> relu -> conv2 -> bn -> relu -> conv3 chain of a bottleneck unit (resnet_v2 `bottleneck`, slim). */
+int stabnet_conv2d_fwd_ex(const float* x, const float* w_ohwi, const float* bias, const float* in_scale,
+                          const float* in_shift, const float* residual, int res_H, int res_W, int res_stride,
+                          const float* out_scale, const float* out_shift, float* y, int N, int H, int W, int Cin,
+                          int Cout, int KH, int KW, int stride, int pad, int relu_out, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* ---- the regressor as one plan --------------------------------------------------------------------------
  * get_resnet(x_tensor, reuse, is_training=False, x_batch_size) -> theta       s_net_bundle_nobm.py:250-264

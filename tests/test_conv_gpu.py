@@ -18,12 +18,24 @@ CASES = [
     (1, 18, 32, 128, 512, 1, 1, 0, True, True, 2, False),    # conv3 + strided identity shortcut
     (1, 9, 16, 512, 512, 3, 1, 1, True, False, 0, True),     # small M, big K -> split-K
     (1, 9, 16, 2048, 512, 1, 1, 0, True, False, 0, False),   # block4 conv1 -> split-K
-    (3, 72, 128, 64, 256, 1, 1, 0, False, True, 0, False),   # big M, 128x128 tile
+    (3, 72, 128, 64, 256, 1, 1, 0, False, True, 0, False),   # big M, no prologue -> LDS-DMA ring kernel, 2 K-steps
+    # ring kernel (no prologue, Cin % 32 == 0): every K-step count of the steady loop / tail split, padding, stride
+    (1, 17, 23, 32, 64, 1, 1, 0, False, False, 0, False),    # 1 K-step, ragged M
+    (1, 17, 23, 96, 96, 1, 1, 0, False, True, 0, True),      # 3 K-steps, ragged Cout tile
+    (1, 17, 23, 128, 64, 1, 1, 0, False, False, 1, False),   # 4 K-steps + residual
+    (1, 17, 23, 160, 64, 1, 1, 0, False, False, 0, False),   # 5 K-steps (first steady iteration)
+    (1, 17, 23, 256, 64, 1, 1, 0, False, False, 0, False),   # 8 K-steps
+    (2, 36, 64, 64, 64, 3, 1, 1, False, False, 0, False),    # 3x3 SAME, zero page taps
+    (1, 37, 63, 128, 128, 3, 2, 1, False, True, 0, True),    # 3x3 stride 2, odd sizes
+    (1, 36, 64, 64, 64, 3, 1, 2, False, False, 0, False),    # pad 2 (full correlation, the stride-1 dgrad geometry)
+    (1, 9, 16, 512, 512, 3, 1, 1, False, False, 0, True),    # split-K through the ring kernel
+    (1, 18, 32, 128, 512, 1, 2, 0, False, True, 2, False),   # strided 1x1 (shortcut) + strided residual read
 ]
 
 
+@pytest.mark.parametrize("out_bn", [False, True])
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad,prologue,bias,res,relu", CASES)
-def test_conv2d_matches_oracle(cuda, N, H, W, Cin, Cout, k, stride, pad, prologue, bias, res, relu):
+def test_conv2d_matches_oracle(cuda, N, H, W, Cin, Cout, k, stride, pad, prologue, bias, res, relu, out_bn):
     from stabnet_amd import ops
     rng = np.random.default_rng(Cin * 7 + Cout + k)
     x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
@@ -41,12 +53,18 @@ def test_conv2d_matches_oracle(cuda, N, H, W, Cin, Cout, k, stride, pad, prologu
     elif res == 2:
         r = rng.standard_normal((N, 2 * Ho - 1, 2 * Wo, Cout)).astype(np.float32)
         want = want + r[:, ::2, ::2, :]
+    osc = osh = None
+    if out_bn:
+        osc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+        osh = (rng.standard_normal(Cout) * 0.3).astype(np.float32)
+        want = (want * osc + osh).astype(np.float32)
     if relu:
         want = np.maximum(want, 0)
     t = lambda v: None if v is None else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(cuda)
-    got = ops.conv2d(t(x), t(ops.pack_conv_weight(w)), t(b), t(sc), t(sh), t(r), 2 if res == 2 else 1, stride, pad, relu)
+    got = ops.conv2d(t(x), t(ops.pack_conv_weight(w)), t(b), t(sc), t(sh), t(r), 2 if res == 2 else 1, stride, pad, relu,
+                     out_scale=t(osc), out_shift=t(osh))
     got = got.cpu().numpy()
     assert got.shape == want.shape
     scale = np.abs(want).max()
     err = np.abs(got - want).max()
-    assert err <= 2e-5 * scale, "max err %g (scale %g)" % (err, scale)
+    assert err <= (4e-5 if out_bn else 2e-5) * scale, "max err %g (scale %g)" % (err, scale)
