@@ -22,6 +22,7 @@ struct ConvArgs {
     int M, K;                // M = N*Ho*Wo, K = KH*KW*Cin
     int splitk, steps_per_split;
     int cin_real;            // un-padded Cin (algorithmic flop accounting only); 0 = Cin
+    int xcd_swizzle;         // 1: remap workgroup ids so each XCD (own 4 MiB L2) works on a contiguous run of M tiles
 };
 
 // Chooses tile shape / split-K and returns the workspace bytes the launch needs (0 if none).

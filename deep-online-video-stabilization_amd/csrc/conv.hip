@@ -112,6 +112,8 @@ static int pick_tile(const ConvArgs& a, int& splitk) {
 }
 
 size_t conv_plan(ConvArgs& a) {
+    static const int swz = env_int("STABNET_CONV_XCD", 1);
+    a.xcd_swizzle = swz;
     a.M = a.N * a.Ho * a.Wo;
     a.K = a.KH * a.KW * a.Cin;
     int splitk = 1;
@@ -125,7 +127,9 @@ size_t conv_plan(ConvArgs& a) {
 
 template <int BM, int BN, int BK, int WM, int WN, int MODE, int NBUF>
 static int launch_one_nb(const ConvArgs& a, hipStream_t st) {
-    constexpr size_t lds = NBUF * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
+    constexpr size_t lds_op = NBUF * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
+    constexpr size_t lds_epi = 4 * (size_t)SN_EPI_WAVE_FLOATS * sizeof(float);        // the epilogue's transposition scratch
+    constexpr size_t lds = lds_op > lds_epi ? lds_op : lds_epi;
     static bool configured = false;
     auto kern = conv_igemm_f32_kernel<BM, BN, BK, WM, WN, MODE, NBUF>;
     if (!configured) {
@@ -183,6 +187,7 @@ static int launch_ring(const ConvArgs& a, hipStream_t st) {
 
 int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof) {
     SN_REQUIRE(a.Cin % 16 == 0, "conv: Cin=%d must be a multiple of 16 (pad the channels)", a.Cin);
+    SN_REQUIRE(a.Cout % 4 == 0, "conv: Cout=%d must be a multiple of 4", a.Cout);
     SN_REQUIRE(a.splitk >= 1 && a.steps_per_split >= 1, "conv: conv_plan() not called");
     SN_REQUIRE(a.splitk == 1 || a.partial != nullptr, "conv: split-K needs a workspace");
     int splitk_unused = 1;

@@ -24,54 +24,102 @@ __device__ unsigned long long* g_conv_stamps;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Epilogue shared by the convolution kernels.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// Workgroup id -> (M tile, N tile, K slice).  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs
+// (MI355X_MICROARCH.md, Workgroup dispatch), each with a private 4 MiB L2: with the identity map every XCD streams the
+// WHOLE input.  The remap gives the ids sharing an XCD (equal id % 8) one contiguous run of logical tiles, N tile fastest:
+// the N tiles of an M tile and the next M tiles (halo rows of a 3x3) then hit in that XCD's L2.  Bijective for any grid
+// size (cdna_hip_programming.md, "XCD swizzle must be bijective"); a speed choice only.
+struct ConvTile { int mt, nt, z; };
+__device__ __forceinline__ ConvTile conv_tile_of_block(const ConvArgs& p) {
+    ConvTile t;
+    if (!p.xcd_swizzle) {
+        t.mt = blockIdx.x; t.nt = blockIdx.y; t.z = blockIdx.z;
+        return t;
+    }
+    const unsigned gm = gridDim.x, gn = gridDim.y, nwg = gm * gn * gridDim.z;
+    const unsigned w = blockIdx.x + gm * (blockIdx.y + gn * blockIdx.z);
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = w & 7;
+    const unsigned L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+    const unsigned mn = L / gn;
+    t.nt = (int)(L - mn * gn);
+    t.z = (int)(mn / gm);
+    t.mt = (int)(mn - (unsigned)t.z * gm);
+    return t;
+}
+
 // y = acc + bias (+ residual) ; y = y*out_scale + out_shift (optional) ; relu (optional); split-K slices store raw partials.
+//
+// The accumulators go through a wave-private LDS scratch ([32][SN_EPI_PITCH] floats per wave, caller provides it and has
+// made sure no wave still reads the LDS it overlays) so that every lane ends up with FOUR CONSECUTIVE CHANNELS of one
+// pixel: residual / bias / BN operands are read and y is written 16 B per lane, 128 B per 8 lanes (the C/D map itself
+// gives 4 B per lane; measured, that form left the store path -- not the MFMAs -- bounding the low-K 1x1 layers).
+// C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  DS operations of one wave execute in
+// order, so the write -> read -> overwrite sequence on the private scratch needs no barrier.  Requires Cout % 4 == 0.
+constexpr int SN_EPI_PITCH = 40;                          // floats; 4*PITCH % 64 == 32 -> conflict-free ds_write_b32
+constexpr int SN_EPI_WAVE_FLOATS = 32 * SN_EPI_PITCH;
+
 template <int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& p, int mw0, int nw0, int lane) {
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& p, int mw0, int nw0, int lane, int z,
+                                              float* scratch) {
     const bool split = p.splitk > 1;
-    float* const outp = split ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : p.y;
+    float* const outp = split ? p.partial + (size_t)z * p.M * p.Cout : p.y;
     const bool has_res = !split && p.residual != nullptr;
     const bool has_obn = !split && p.out_scale != nullptr;
+    const bool has_bias = !split && p.bias != nullptr;
+    const bool relu = !split && p.relu_out;
     const bool res_plain = p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo;
+    float* const wr = scratch + (4 * (lane >> 5)) * SN_EPI_PITCH + (lane & 31);        // C/D role
+    const int rrow = lane >> 3, rc4 = (lane & 7) * 4;                                   // row-major role: rows rrow + 8*q
+    const float* const rd = scratch + rrow * SN_EPI_PITCH + rc4;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int mrow0 = mw0 + i * 32 + 4 * (lane >> 5);
-        int roff[16];                                     // residual element offset of each accumulator row
-        if (has_res) {
+        int mrow[4];
+        unsigned roff[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = min(mrow0 + (r & 3) + 8 * (r >> 2), p.M - 1);
-                if (res_plain) {
-                    roff[r] = m * p.Cout;
-                } else {
-                    const int img = m / (p.Ho * p.Wo);
-                    const int rr = m - img * (p.Ho * p.Wo);
-                    const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
-                    roff[r] = ((img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.Cout;
-                }
+        for (int q = 0; q < 4; ++q) {
+            mrow[q] = mw0 + i * 32 + rrow + 8 * q;
+            const int m = min(mrow[q], p.M - 1);
+            if (!has_res || res_plain) {
+                roff[q] = (unsigned)(m * p.Cout);
+            } else {
+                const int img = m / (p.Ho * p.Wo);
+                const int rr = m - img * (p.Ho * p.Wo);
+                const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
+                roff[q] = (unsigned)(((img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.Cout);
             }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = nw0 + j * 32 + (lane & 31);
+            const int n = nw0 + j * 32 + rc4;
             const bool ncol = n < p.Cout;
-            const int nc = min(n, p.Cout - 1);
-            const float bv = (!split && p.bias != nullptr) ? p.bias[nc] : 0.f;
-            const float os = has_obn ? p.out_scale[nc] : 1.f, ob = has_obn ? p.out_shift[nc] : 0.f;
-            float rv[16];
+            const int nc = min(n, p.Cout - 4);
+            float4 rv[4];
             if (has_res) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) rv[r] = p.residual[(unsigned)(roff[r] + nc)];
+                for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const float4*>(p.residual + (roff[q] + (unsigned)nc));
             }
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 bv = has_bias ? *reinterpret_cast<const float4*>(p.bias + nc) : zero4;
+            const float4 os = has_obn ? *reinterpret_cast<const float4*>(p.out_scale + nc) : zero4;
+            const float4 ob = has_obn ? *reinterpret_cast<const float4*>(p.out_shift + nc) : zero4;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-                float v = acc[i][j][r] + bv;
-                if (has_res) v += rv[r];
-                if (has_obn) v = __builtin_fmaf(v, os, ob);
-                if (!split && p.relu_out) v = fmaxf(v, 0.f);
-                if (!(CONV_ABLATE & 4)) { if (ncol && m < p.M) outp[(size_t)m * p.Cout + n] = v; }
-                else if (v == 123.456f) outp[0] = v;
+            for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * SN_EPI_PITCH] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = *reinterpret_cast<const float4*>(rd + 8 * q * SN_EPI_PITCH);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (has_res) { v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w; }
+                if (has_obn) {
+                    v.x = __builtin_fmaf(v.x, os.x, ob.x); v.y = __builtin_fmaf(v.y, os.y, ob.y);
+                    v.z = __builtin_fmaf(v.z, os.z, ob.z); v.w = __builtin_fmaf(v.w, os.w, ob.w);
+                }
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (!(CONV_ABLATE & 4)) {
+                    if (ncol && mrow[q] < p.M) *reinterpret_cast<float4*>(outp + ((size_t)mrow[q] * p.Cout + n)) = v;
+                } else if (v.x == 123.456f) outp[0] = v.x;
             }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -97,11 +145,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
     CONV_STAMP_AT(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const ConvTile tile = conv_tile_of_block(p);
+    const int m0 = tile.mt * BM, n0 = tile.nt * BN;
 
     const int cin_steps = p.Cin / BK;
     const int total_steps = p.KH * p.KW * cin_steps;
-    const int ks_begin = blockIdx.z * p.steps_per_split;
+    const int ks_begin = tile.z * p.steps_per_split;
     const int ks_end = min(total_steps, ks_begin + p.steps_per_split);
 
     // ---- loader mapping: thread -> (row within pass, float4 within the BK slice).
@@ -301,7 +350,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
     }
 
     CONV_STAMP_AT(2);
-    conv_epilogue<TM, TN>(acc, p, m0 + wm * WM, n0 + wn * WN, lane);
+    __syncthreads();                                       // every wave is done with the operand stages the scratch overlays
+    conv_epilogue<TM, TN>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, tile.z, smem + wave * SN_EPI_WAVE_FLOATS);
     CONV_STAMP_AT(3);
 }
 

@@ -18,6 +18,10 @@
 #include "conv_kernel.h"
 #include <type_traits>
 
+#ifndef RING_ABLATE
+#define RING_ABLATE 0          // probe-only bit mask (tools/ring_probe.hip): 1 no DMA, 2 no barrier, 4 no ds_read, 8 no MFMA
+#endif
+
 typedef __attribute__((address_space(3))) void* sn_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* sn_gbl_ptr_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -34,10 +38,11 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     CONV_STAMP_AT(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const ConvTile tile = conv_tile_of_block(p);
+    const int m0 = tile.mt * BM, n0 = tile.nt * BN;
     const int cin_steps = p.Cin / BK;
     const int total_steps = p.KH * p.KW * cin_steps;
-    const int ks_begin = blockIdx.z * p.steps_per_split;
+    const int ks_begin = tile.z * p.steps_per_split;
     const int ks_end = min(total_steps, ks_begin + p.steps_per_split);
     const int nsteps = ks_end - ks_begin;
 
@@ -91,6 +96,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     const float* const zero_page = g_conv_zero_page;
 
     auto issue = [&](float* const st) {
+        if (RING_ABLATE & 1) return;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const float* src = xb + a_voff[t];
@@ -124,13 +130,18 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     // depends on and puts `s_waitcnt vmcnt(0)` in front of compiler-visible LDS loads, draining the stage that was just
     // put in flight.  Waits are therefore explicit: vmcnt before the barrier, lgkmcnt (tied to the fragment registers
     // through "+v" so the MFMAs cannot move above them) before each MFMA group.
-#define SN_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define SN_DS_READ(dst, addr, off)                                                                        \
+    do { if (!(RING_ABLATE & 4)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off)); } while (0)
 #define SN_LGKM_WAIT(n, a, b) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b))
-#define SN_MFMA4(a, b)                                                                    \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);       \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[0][0], 0, 0, 0);       \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[0][0], 0, 0, 0);       \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[0][0], 0, 0, 0);
+#define SN_MFMA4(a, b)                                                                        \
+    if (!(RING_ABLATE & 8)) {                                                                 \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);       \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[0][0], 0, 0, 0);       \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[0][0], 0, 0, 0);       \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[0][0], 0, 0, 0);       \
+    } else {                                                                                  \
+        acc[0][0][0] += a.x * b.x;                                                            \
+    }
 
     auto step = [&](auto steady, auto slot_c, int k) {
         constexpr int SLOT = decltype(slot_c)::value;
@@ -139,10 +150,11 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         // stage k has landed for THIS wave when at most the next stage's DMAs are outstanding (4 per stage per wave)
         if (decltype(steady)::value || k + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // stage k complete for all waves; stage k-1 no longer read
+        if (!(RING_ABLATE & 2)) __builtin_amdgcn_s_barrier();   // stage k complete for all waves; stage k-1 no longer read
         __builtin_amdgcn_sched_barrier(0);
         if (decltype(steady)::value || k + 2 < nsteps) issue(ring + ISSUE_SLOT * STAGE);   // overwrites stage k-1's slot
         f32x4 a0, b0, a1, b1;
+        if (RING_ABLATE & 4) { a0 = b0 = a1 = b1 = f32x4{1.f, 2.f, 3.f, 4.f}; }
         SN_DS_READ(a0, a_frag[0], OFF);
         SN_DS_READ(b0, b_frag[0], OFF);
         SN_DS_READ(a1, a_frag[1], OFF);
@@ -184,6 +196,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
 #undef SN_LGKM_WAIT
 #undef SN_MFMA4
     CONV_STAMP_AT(2);
-    conv_epilogue<1, 1>(acc, p, m0 + wm * 32, n0 + wn * 32, lane);
+    __syncthreads();                                       // every wave is done with the last stage
+    conv_epilogue<1, 1>(acc, p, m0 + wm * 32, n0 + wn * 32, lane, tile.z, ring + wave * SN_EPI_WAVE_FLOATS);
     CONV_STAMP_AT(3);
 }
