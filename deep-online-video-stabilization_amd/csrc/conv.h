@@ -22,6 +22,7 @@ struct ConvArgs {
     int M, K;                // M = N*Ho*Wo, K = KH*KW*Cin
     int splitk, steps_per_split;
     int cin_real;            // un-padded Cin (algorithmic flop accounting only); 0 = Cin
+    unsigned div_hw_mul, div_hw_shift, div_w_mul, div_w_shift;   // exact m / (Ho*Wo) and r / Wo by multiply-high (conv_plan)
     int xcd_swizzle;         // 1: remap workgroup ids so each XCD (own 4 MiB L2) works on a contiguous run of M tiles
 };
 
@@ -30,3 +31,19 @@ size_t conv_plan(ConvArgs& a);
 // Enqueues the convolution (and the split-K reduction when a.splitk > 1).
 struct Prof;
 int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof = nullptr);
+
+// Exact unsigned division by an invariant divisor d >= 1 for numerators n < 2^31 (Granlund-Montgomery round-up form):
+//   l = ceil(log2 d), mul = floor(2^32 (2^l - d) / d) + 1, n / d = (mulhi(mul, n) + n) >> l.
+// Three instructions instead of the ~40 of a software 32-bit division; the kernels' per-tile index setup is VALU work
+// that competes with the MFMAs for issue slots.
+static inline void sn_fastdiv_make(unsigned d, unsigned& mul, unsigned& shift) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    shift = l;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ int sn_fastdiv(int n, unsigned mul, unsigned shift) {
+    return (int)((__umulhi(mul, (unsigned)n) + (unsigned)n) >> shift);
+}
+#endif

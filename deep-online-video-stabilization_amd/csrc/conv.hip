@@ -45,9 +45,9 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
         if (p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo) {
             ri = (size_t)m * p.Cout + n;
         } else {
-            const int img = m / (p.Ho * p.Wo);
+            const int img = sn_fastdiv(m, p.div_hw_mul, p.div_hw_shift);
             const int rr = m - img * (p.Ho * p.Wo);
-            const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
+            const int oy = sn_fastdiv(rr, p.div_w_mul, p.div_w_shift), ox = rr - oy * p.Wo;
             ri = (((size_t)img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.Cout + n;
         }
         const float4 t = *reinterpret_cast<const float4*>(p.residual + ri);
@@ -112,10 +112,12 @@ static int pick_tile(const ConvArgs& a, int& splitk) {
 }
 
 size_t conv_plan(ConvArgs& a) {
-    static const int swz = env_int("STABNET_CONV_XCD", 1);
+    static const int swz = env_int("STABNET_CONV_XCD", 0);   // measured: no gain at these sizes
     a.xcd_swizzle = swz;
     a.M = a.N * a.Ho * a.Wo;
     a.K = a.KH * a.KW * a.Cin;
+    sn_fastdiv_make((unsigned)(a.Ho * a.Wo), a.div_hw_mul, a.div_hw_shift);
+    sn_fastdiv_make((unsigned)a.Wo, a.div_w_mul, a.div_w_shift);
     int splitk = 1;
     (void)pick_tile(a, splitk);
     const int bk = conv_bk(a);
@@ -128,7 +130,7 @@ size_t conv_plan(ConvArgs& a) {
 template <int BM, int BN, int BK, int WM, int WN, int MODE, int NBUF>
 static int launch_one_nb(const ConvArgs& a, hipStream_t st) {
     constexpr size_t lds_op = NBUF * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
-    constexpr size_t lds_epi = 4 * (size_t)SN_EPI_WAVE_FLOATS * sizeof(float);        // the epilogue's transposition scratch
+    constexpr size_t lds_epi = 4 * (size_t)SN_EPI_WAVE_BYTES;        // the epilogue's transposition scratch
     constexpr size_t lds = lds_op > lds_epi ? lds_op : lds_epi;
     static bool configured = false;
     auto kern = conv_igemm_f32_kernel<BM, BN, BK, WM, WN, MODE, NBUF>;
@@ -163,32 +165,43 @@ static int launch_one(const ConvArgs& a, hipStream_t st) {
 }
 
 // LDS-DMA ring kernel (conv_ring_kernel.h): no A-operand prologue, stride-free addressing, Cin % 32 == 0, 64x64 tile.
-static int g_ring = -1, g_ring_ns = 3;
+static int g_ring = -1;
 
 static bool ring_eligible(const ConvArgs& a, int tile) {
     if (g_ring < 0) {
         g_ring = env_int("STABNET_CONV_RING", 1);
-        g_ring_ns = env_int("STABNET_CONV_RING_NS", 3);
     }
     return g_ring && tile == T64x64 && a.in_scale == nullptr && a.up == 1 && a.Cin % 32 == 0 && !g_force_bk16;
 }
 
-template <int MODE, int NS>
-static int launch_ring_ns(const ConvArgs& a, hipStream_t st) {
-    dim3 grid(cdiv(a.M, 64), cdiv(a.Cout, 64), a.splitk);
-    conv_ring_f32_kernel<MODE, NS><<<grid, 256, 0, st>>>(a);
+static int g_ring_wgs = 0;        // resident workgroups of the ring kernel on this device (3 per CU: 48 KiB LDS each)
+
+template <int MODE>
+static int launch_ring_mode(const ConvArgs& a, hipStream_t st) {
+    if (g_ring_wgs == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus <= 0) {
+            stabnet_set_error("conv: cannot read the CU count");
+            return STABNET_ERR_LAUNCH;
+        }
+        g_ring_wgs = env_int("STABNET_CONV_RING_WGS_PER_CU", 3) * cus;
+    }
+    const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64) * a.splitk;
+    const int grid = (int)std::min<long>(ntiles, g_ring_wgs);
+    conv_ring_f32_kernel<MODE><<<grid, 256, 0, st>>>(a);
     SN_LAUNCH_CHECK("conv_ring_f32_kernel");
     return STABNET_OK;
 }
 
 static int launch_ring(const ConvArgs& a, hipStream_t st) {
-    return a.pad == 0 ? launch_ring_ns<0, 3>(a, st) : launch_ring_ns<1, 3>(a, st);
+    return a.pad == 0 ? launch_ring_mode<0>(a, st) : launch_ring_mode<1>(a, st);
 }
 
 int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof) {
     SN_REQUIRE(a.Cin % 16 == 0, "conv: Cin=%d must be a multiple of 16 (pad the channels)", a.Cin);
     SN_REQUIRE(a.Cout % 4 == 0, "conv: Cout=%d must be a multiple of 4", a.Cout);
-    SN_REQUIRE(a.splitk >= 1 && a.steps_per_split >= 1, "conv: conv_plan() not called");
+    SN_REQUIRE(a.splitk >= 1 && a.steps_per_split >= 1 && a.div_hw_mul != 0, "conv: conv_plan() not called");
     SN_REQUIRE(a.splitk == 1 || a.partial != nullptr, "conv: split-K needs a workspace");
     int splitk_unused = 1;
     const int t = pick_tile(a, splitk_unused);

@@ -49,18 +49,23 @@ __device__ __forceinline__ ConvTile conv_tile_of_block(const ConvArgs& p) {
 
 // y = acc + bias (+ residual) ; y = y*out_scale + out_shift (optional) ; relu (optional); split-K slices store raw partials.
 //
-// The accumulators go through a wave-private LDS scratch ([32][SN_EPI_PITCH] floats per wave, caller provides it and has
-// made sure no wave still reads the LDS it overlays) so that every lane ends up with FOUR CONSECUTIVE CHANNELS of one
-// pixel: residual / bias / BN operands are read and y is written 16 B per lane, 128 B per 8 lanes (the C/D map itself
-// gives 4 B per lane; measured, that form left the store path -- not the MFMAs -- bounding the low-K 1x1 layers).
-// C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  DS operations of one wave execute in
-// order, so the write -> read -> overwrite sequence on the private scratch needs no barrier.  Requires Cout % 4 == 0.
-constexpr int SN_EPI_PITCH = 40;                          // floats; 4*PITCH % 64 == 32 -> conflict-free ds_write_b32
-constexpr int SN_EPI_WAVE_FLOATS = 32 * SN_EPI_PITCH;
+// The accumulators go through a wave-private LDS scratch ([32][32] floats = 4 KiB per wave; the caller provides its LDS
+// byte address and has made sure no wave still reads the LDS it overlays) so that every lane ends up with FOUR CONSECUTIVE
+// CHANNELS of one pixel: residual / bias / BN operands are read and y is written 16 B per lane, 128 B per 8 lanes (the
+// C/D map itself gives 4 B per lane; measured, that form left the store path -- not the MFMAs -- bounding the low-K 1x1
+// layers).  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  DS operations of one wave
+// execute in order, so the write -> read -> overwrite sequence on the private scratch needs no barrier.  The LDS accesses
+// are inline asm: compiler-visible LDS accesses next to in-flight LDS-DMA get an `s_waitcnt vmcnt(0)` from the compiler
+// (see conv_ring_kernel.h), which would drain the next tile's prefetch.  Requires Cout % 4 == 0.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SN_EPI_WAVE_BYTES = 32 * 32 * 4;
+
+#define SN_EPI_W(r) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(wr), "v"(a[r]), "n"((((r) & 3) + 8 * ((r) >> 2)) * 128) : "memory")
+#define SN_EPI_R(q, dst) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(rd), "n"((q) * 1024) : "memory")
 
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& p, int mw0, int nw0, int lane, int z,
-                                              float* scratch) {
+                                              unsigned scratch) {
     const bool split = p.splitk > 1;
     float* const outp = split ? p.partial + (size_t)z * p.M * p.Cout : p.y;
     const bool has_res = !split && p.residual != nullptr;
@@ -68,9 +73,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvA
     const bool has_bias = !split && p.bias != nullptr;
     const bool relu = !split && p.relu_out;
     const bool res_plain = p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo;
-    float* const wr = scratch + (4 * (lane >> 5)) * SN_EPI_PITCH + (lane & 31);        // C/D role
-    const int rrow = lane >> 3, rc4 = (lane & 7) * 4;                                   // row-major role: rows rrow + 8*q
-    const float* const rd = scratch + rrow * SN_EPI_PITCH + rc4;
+    const unsigned wr = scratch + (unsigned)(((4 * (lane >> 5)) * 32 + (lane & 31)) * 4);   // C/D role
+    const int rrow = lane >> 3, rc4 = (lane & 7) * 4;                                        // row-major role: rows rrow + 8q
+    const unsigned rd = scratch + (unsigned)((rrow * 32 + rc4) * 4);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         int mrow[4];
@@ -82,9 +87,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvA
             if (!has_res || res_plain) {
                 roff[q] = (unsigned)(m * p.Cout);
             } else {
-                const int img = m / (p.Ho * p.Wo);
+                const int img = sn_fastdiv(m, p.div_hw_mul, p.div_hw_shift);
                 const int rr = m - img * (p.Ho * p.Wo);
-                const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
+                const int oy = sn_fastdiv(rr, p.div_w_mul, p.div_w_shift), ox = rr - oy * p.Wo;
                 roff[q] = (unsigned)(((img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.Cout);
             }
         }
@@ -102,12 +107,17 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvA
             const float4 bv = has_bias ? *reinterpret_cast<const float4*>(p.bias + nc) : zero4;
             const float4 os = has_obn ? *reinterpret_cast<const float4*>(p.out_scale + nc) : zero4;
             const float4 ob = has_obn ? *reinterpret_cast<const float4*>(p.out_shift + nc) : zero4;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * SN_EPI_PITCH] = acc[i][j][r];
-            __builtin_amdgcn_wave_barrier();
+            {
+                const f32x16 a = acc[i][j];
+                SN_EPI_W(0); SN_EPI_W(1); SN_EPI_W(2); SN_EPI_W(3); SN_EPI_W(4); SN_EPI_W(5); SN_EPI_W(6); SN_EPI_W(7);
+                SN_EPI_W(8); SN_EPI_W(9); SN_EPI_W(10); SN_EPI_W(11); SN_EPI_W(12); SN_EPI_W(13); SN_EPI_W(14); SN_EPI_W(15);
+            }
+            f32x4 t[4];
+            SN_EPI_R(0, t[0]); SN_EPI_R(1, t[1]); SN_EPI_R(2, t[2]); SN_EPI_R(3, t[3]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])::"memory");
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float4 v = *reinterpret_cast<const float4*>(rd + 8 * q * SN_EPI_PITCH);
+                float4 v = make_float4(t[q].x, t[q].y, t[q].z, t[q].w);
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 if (has_res) { v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w; }
                 if (has_obn) {
@@ -119,7 +129,6 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvA
                     if (ncol && mrow[q] < p.M) *reinterpret_cast<float4*>(outp + ((size_t)mrow[q] * p.Cout + n)) = v;
                 } else if (v.x == 123.456f) outp[0] = v.x;
             }
-            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -168,9 +177,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
     for (int ps = 0; ps < A_PASSES; ++ps) {
         const int m = m0 + lrow + ps * ROWS_PER_PASS;
         const int mc = min(m, p.M - 1);
-        const int img = mc / (p.Ho * p.Wo);
+        const int img = sn_fastdiv(mc, p.div_hw_mul, p.div_hw_shift);
         const int r = mc - img * (p.Ho * p.Wo);
-        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        const int oy = sn_fastdiv(r, p.div_w_mul, p.div_w_shift), ox = r - oy * p.Wo;
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
         a_iy0[ps] = iy0;
         a_ix0[ps] = ix0;
@@ -351,7 +360,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
 
     CONV_STAMP_AT(2);
     __syncthreads();                                       // every wave is done with the operand stages the scratch overlays
-    conv_epilogue<TM, TN>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, tile.z, smem + wave * SN_EPI_WAVE_FLOATS);
+    conv_epilogue<TM, TN>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, tile.z,
+                          (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem + wave * SN_EPI_WAVE_BYTES);
     CONV_STAMP_AT(3);
 }
 

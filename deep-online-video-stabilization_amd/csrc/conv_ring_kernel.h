@@ -1,11 +1,11 @@
-// Implicit-GEMM convolution, LDS-DMA ring variant (gfx950, exact float32 MFMA).
+// Implicit-GEMM convolution, persistent LDS-DMA ring variant (gfx950, exact float32 MFMA).
 //
 // For convolutions whose A operand needs no prologue (the input is already activated, or is a raw gradient): tiles go
 // HBM/L2 -> LDS directly with `global_load_lds` (16 B per lane, no VGPR staging, no ds_write, no VALU on the data),
-// through a ring of NS stages.  Measured motivation: with register staging the K-loop of the v1
+// through a ring of 3 stages.  Measured motivation: with register staging the K-loop of the v1
 // kernel is capped by (a) VALU work competing with the f32 MFMAs and (b) one K-step of load latency hiding.
 //
-//   block  : 64 x 64 output tile, 256 threads = 4 waves (2 x 2 of 32 x 32), BK = 32, NS = 3 stages of 16 KiB
+//   block  : 64 x 64 output tile, 256 threads = 4 waves (2 x 2 of 32 x 32), BK = 32, 3 stages of 16 KiB
 //   stage  : A [64 rows][32 floats] then B [64 rows][32 floats], rows UNPADDED (a DMA instruction writes 1 KiB = 8 rows
 //            contiguously); bank conflicts of the ds_read_b128 fragment reads are avoided by an XOR swizzle of the 16-B
 //            chunk index, chunk_phys = chunk ^ ((row >> 1) & 7), applied on the SOURCE address of the DMA lane and on
@@ -14,6 +14,11 @@
 //   sync   : counted `s_waitcnt vmcnt(4)` (the next stage stays in flight) + ONE raw s_barrier per K-step, which both
 //            publishes stage k and retires every wave's reads of stage k-1 (the slot the new DMA overwrites)
 //   padding: out-of-frame taps read a 16-B zero page (no prologue => zeros stay zeros, nothing to mask afterwards)
+//   persist: the grid is at most 3 workgroups per CU; workgroup b walks tiles b, b+G, b+2G, ... and the ring runs ACROSS
+//            tile boundaries: the producer side (DMA issue) is two K-steps ahead of the consumer side (MFMA), so the
+//            first stages of the next tile are in flight while the current tile's epilogue runs.  The epilogue's
+//            transposition scratch overlays the stage that was consumed last (free until the step after next issues
+//            into it, behind a barrier).
 #pragma once
 #include "conv_kernel.h"
 #include <type_traits>
@@ -24,60 +29,127 @@
 
 typedef __attribute__((address_space(3))) void* sn_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* sn_gbl_ptr_t;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __attribute__((aligned(16))) float g_conv_zero_page[8];      // zero-initialised device storage
 
-template <int MODE /* 0: no padding, 1: zero padding */, int NS>
+template <int MODE /* 0: no padding, 1: zero padding */>
 __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     constexpr int BM = 64, BN = 64, BK = 32;
     constexpr int STAGE = (BM + BN) * BK;                  // floats
-    static_assert(NS == 3, "the K loop is unrolled over a ring of exactly 3 stages");
-    __shared__ __attribute__((aligned(16))) float ring[NS * STAGE];
+    __shared__ __attribute__((aligned(16))) float ring[3 * STAGE];
 
-    CONV_STAMP_AT(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const ConvTile tile = conv_tile_of_block(p);
-    const int m0 = tile.mt * BM, n0 = tile.nt * BN;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.Cout + BN - 1) / BN;
+    const int tiles_mn = tiles_m * tiles_n;
+    const int ntiles = tiles_mn * p.splitk;                // K slice slowest, then M tile, N tile fastest
+    const int G = gridDim.x;
     const int cin_steps = p.Cin / BK;
     const int total_steps = p.KH * p.KW * cin_steps;
-    const int ks_begin = tile.z * p.steps_per_split;
-    const int ks_end = min(total_steps, ks_begin + p.steps_per_split);
-    const int nsteps = ks_end - ks_begin;
+    const int last_slice_steps = total_steps - (p.splitk - 1) * p.steps_per_split;
+    const unsigned lds_base = (unsigned)(size_t)(sn_lds_ptr_t)ring;
 
-    // ---- DMA lane mapping: instruction g in {wave, wave + 4} covers tile rows 8g .. 8g+7
+    // consumer steps of this workgroup (every slice has steps_per_split steps except the last one)
+    int remaining = 0;
+    for (int t = blockIdx.x; t < ntiles; t += G) remaining += (t / tiles_mn == p.splitk - 1) ? last_slice_steps : p.steps_per_split;
+
+    // ---- DMA lane roles: instruction g in {wave, wave + 4} covers tile rows 8g .. 8g+7
     const int rr = lane >> 3, cp = lane & 7;
     const int pad_off = (p.pad * p.W + p.pad) * p.Cin;
+    const int row_jump = (p.W - p.KW) * p.Cin;
+    const float* const zero_page = g_conv_zero_page;
+
+    // ---- producer state: the tile whose stages are being issued
+    int pt = blockIdx.x;                                   // tile id; >= ntiles: exhausted
+    int p_left = 0;                                        // stages of tile `pt` still to issue
     unsigned a_voff[2], w_voff[2];
     unsigned long long a_mask[2];
+    int l_tap = 0, l_c0 = 0, l_kw = 0;
+    const float *xb = p.x, *wb = p.w;
+    auto producer_setup = [&]() {
+        const int z = pt / tiles_mn;
+        const int mn = pt - z * tiles_mn;
+        const int mt = mn / tiles_n, nt = mn - mt * tiles_n;
+        const int m0 = mt * BM, n0 = nt * BN;
+        const int ks_begin = z * p.steps_per_split;
+        p_left = (z == p.splitk - 1) ? last_slice_steps : p.steps_per_split;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int row = 8 * (wave + 4 * t) + rr;
-        const int cl = cp ^ ((row >> 1) & 7);              // logical chunk this lane fetches (swizzle on the source side)
-        const int m = m0 + row;
-        const int mc = min(m, p.M - 1);
-        const int img = mc / (p.Ho * p.Wo);
-        const int r = mc - img * (p.Ho * p.Wo);
-        const int oy = r / p.Wo, ox = r - oy * p.Wo;
-        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-        a_voff[t] = (unsigned)(((img * p.H + iy0 + p.pad) * p.W + ix0 + p.pad) * p.Cin + cl * 4);
-        unsigned long long mk = 0;
-        if (MODE == 1 && m < p.M) {
-            for (int kh = 0; kh < p.KH; ++kh)
-                for (int kw = 0; kw < p.KW; ++kw)
-                    if ((unsigned)(iy0 + kh) < (unsigned)p.H && (unsigned)(ix0 + kw) < (unsigned)p.W)
-                        mk |= 1ull << (kh * p.KW + kw);
+        for (int t = 0; t < 2; ++t) {
+            const int row = 8 * (wave + 4 * t) + rr;
+            const int cl = cp ^ ((row >> 1) & 7);          // logical chunk this lane fetches (swizzle on the source side)
+            const int m = m0 + row;
+            const int mc = min(m, p.M - 1);
+            const int img = sn_fastdiv(mc, p.div_hw_mul, p.div_hw_shift);
+            const int r = mc - img * (p.Ho * p.Wo);
+            const int oy = sn_fastdiv(r, p.div_w_mul, p.div_w_shift), ox = r - oy * p.Wo;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            a_voff[t] = (unsigned)(((img * p.H + iy0 + p.pad) * p.W + ix0 + p.pad) * p.Cin + cl * 4);
+            unsigned long long mk = 0;
+            if (MODE == 1 && m < p.M) {
+                // taps (kh, kw) in frame: kh in [kh_lo, kh_hi), kw in [kw_lo, kw_hi): a run of KW-bit row patterns
+                const int kh_lo = max(0, -iy0), kh_hi = min(p.KH, p.H - iy0);
+                const int kw_lo = max(0, -ix0), kw_hi = min(p.KW, p.W - ix0);
+                if (kh_hi > kh_lo && kw_hi > kw_lo) {
+                    const unsigned long long rowbits = ((1ull << (kw_hi - kw_lo)) - 1ull) << kw_lo;
+                    for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * p.KW);
+                }
+            }
+            a_mask[t] = mk;
+            const int n = min(n0 + row, p.Cout - 1);       // rows >= Cout are never stored
+            w_voff[t] = (unsigned)(n * p.K + cl * 4);
         }
-        a_mask[t] = mk;
-        const int n = min(n0 + row, p.Cout - 1);           // rows >= Cout are never stored
-        w_voff[t] = (unsigned)(n * p.K + cl * 4);
-    }
+        l_tap = ks_begin / cin_steps;
+        l_c0 = (ks_begin - l_tap * cin_steps) * BK;
+        const int l_kh = l_tap / p.KW;
+        l_kw = l_tap - l_kh * p.KW;
+        xb = p.x + ((l_kh * p.W + l_kw) * p.Cin + l_c0 - pad_off);
+        wb = p.w + (l_tap * p.Cin + l_c0);
+    };
+    // issue one stage into `st` (no-op when every tile of this workgroup has been issued)
+    auto issue = [&](float* const st) {
+        if (pt >= ntiles) return;
+        if (!(RING_ABLATE & 1)) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float* src = xb + a_voff[t];
+                if (MODE == 1) src = ((a_mask[t] >> l_tap) & 1ull) ? src : zero_page;
+                __builtin_amdgcn_global_load_lds((sn_gbl_ptr_t)src, (sn_lds_ptr_t)(st + (wave + 4 * t) * 256), 16, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                __builtin_amdgcn_global_load_lds((sn_gbl_ptr_t)(wb + w_voff[t]),
+                                                 (sn_lds_ptr_t)(st + BM * BK + (wave + 4 * t) * 256), 16, 0, 0);
+        }
+        if (--p_left == 0) {
+            pt += G;
+            if (pt < ntiles) producer_setup();
+            return;
+        }
+        xb += BK;
+        wb += BK;
+        l_c0 += BK;
+        if (l_c0 == p.Cin) {
+            l_c0 = 0;
+            ++l_tap;
+            if (++l_kw == p.KW) { l_kw = 0; xb += row_jump; }
+        }
+    };
+
+    // ---- consumer state: the tile being accumulated
+    int ct = blockIdx.x, c_left = 0, c_m0 = 0, c_n0 = 0, c_z = 0;
+    auto consumer_setup = [&]() {
+        c_z = ct / tiles_mn;
+        const int mn = ct - c_z * tiles_mn;
+        const int mt = mn / tiles_n;
+        c_m0 = mt * BM;
+        c_n0 = (mn - mt * tiles_n) * BN;
+        c_left = (c_z == p.splitk - 1) ? last_slice_steps : p.steps_per_split;
+    };
+
     // ---- fragment read addresses (LDS bytes, stage 0) of the 4 kk sub-steps: lane (i = lane&31, h = lane>>5) reads
     //      logical chunk 2kk+h; the stage is selected by the immediate offset of the ds_read
     unsigned a_frag[4], b_frag[4];
     {
-        const unsigned lds_base = (unsigned)(size_t)(sn_lds_ptr_t)ring;
         const int ra = wm * 32 + (lane & 31), rb = wn * 32 + (lane & 31), h = lane >> 5;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -86,45 +158,15 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         }
     }
 
-    // ---- K-iteration state of the next stage to issue (wave-uniform running pointers, see conv_kernel.h)
-    int l_tap = ks_begin / cin_steps;
-    int l_c0 = (ks_begin - l_tap * cin_steps) * BK;
-    int l_kh = l_tap / p.KW, l_kw = l_tap - (l_tap / p.KW) * p.KW;
-    const float* xb = p.x + ((l_kh * p.W + l_kw) * p.Cin + l_c0 - pad_off);
-    const float* wb = p.w + (l_tap * p.Cin + l_c0);
-    const int row_jump = (p.W - p.KW) * p.Cin;
-    const float* const zero_page = g_conv_zero_page;
-
-    auto issue = [&](float* const st) {
-        if (RING_ABLATE & 1) return;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float* src = xb + a_voff[t];
-            if (MODE == 1) src = ((a_mask[t] >> l_tap) & 1ull) ? src : zero_page;
-            __builtin_amdgcn_global_load_lds((sn_gbl_ptr_t)src, (sn_lds_ptr_t)(st + (wave + 4 * t) * 256), 16, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-            __builtin_amdgcn_global_load_lds((sn_gbl_ptr_t)(wb + w_voff[t]),
-                                             (sn_lds_ptr_t)(st + BM * BK + (wave + 4 * t) * 256), 16, 0, 0);
-        xb += BK;
-        wb += BK;
-        l_c0 += BK;
-        if (l_c0 == p.Cin) {
-            l_c0 = 0;
-            ++l_tap;
-            if (++l_kw == p.KW) { l_kw = 0; ++l_kh; xb += row_jump; }
-        }
-    };
-
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
 
-    // prologue: two stages in flight
-    if (0 < nsteps) issue(ring);
-    if (1 < nsteps) issue(ring + STAGE);
-    CONV_STAMP_AT(1);
+    if (remaining == 0) return;                            // (the grid never exceeds the tile count; kept for safety)
+    producer_setup();
+    consumer_setup();
+    issue(ring);                                           // two stages in flight
+    issue(ring + STAGE);
 
     // The fragment reads are inline asm on purpose: the compiler's waitcnt insertion cannot tell which DMA a ds_read
     // depends on and puts `s_waitcnt vmcnt(0)` in front of compiler-visible LDS loads, draining the stage that was just
@@ -143,16 +185,19 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         acc[0][0][0] += a.x * b.x;                                                            \
     }
 
-    auto step = [&](auto steady, auto slot_c, int k) {
+    // One K-step on ring slot SLOT; returns false after the workgroup's last step.
+    auto step = [&](auto slot_c) -> bool {
         constexpr int SLOT = decltype(slot_c)::value;
         constexpr int ISSUE_SLOT = (SLOT + 2) % 3;
         constexpr int OFF = SLOT * STAGE * 4;
-        // stage k has landed for THIS wave when at most the next stage's DMAs are outstanding (4 per stage per wave)
-        if (decltype(steady)::value || k + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // This stage has landed for THIS wave when at most the next stage's 4 DMAs are outstanding.  (Epilogue stores of
+        // the previous tile may still be in flight behind them: the counter retires in order, so the wait is then
+        // stricter than needed, never weaker.)
+        if (remaining > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(RING_ABLATE & 2)) __builtin_amdgcn_s_barrier();   // stage k complete for all waves; stage k-1 no longer read
+        if (!(RING_ABLATE & 2)) __builtin_amdgcn_s_barrier();   // stage complete for all waves; previous slot no longer read
         __builtin_amdgcn_sched_barrier(0);
-        if (decltype(steady)::value || k + 2 < nsteps) issue(ring + ISSUE_SLOT * STAGE);   // overwrites stage k-1's slot
+        issue(ring + ISSUE_SLOT * STAGE);                       // overwrites the slot consumed by the previous step
         f32x4 a0, b0, a1, b1;
         if (RING_ABLATE & 4) { a0 = b0 = a1 = b1 = f32x4{1.f, 2.f, 3.f, 4.f}; }
         SN_DS_READ(a0, a_frag[0], OFF);
@@ -175,28 +220,28 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         SN_LGKM_WAIT(0, a1, b1);
         SN_MFMA4(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
+        --remaining;
+        if (--c_left == 0) {
+            __builtin_amdgcn_s_barrier();                  // every wave is done reading slot SLOT: it becomes the scratch
+            __builtin_amdgcn_sched_barrier(0);             // (raw barrier: __syncthreads() would also drain the DMA queue)
+            conv_epilogue<1, 1>(acc, p, c_m0 + wm * 32, c_n0 + wn * 32, lane, c_z,
+                                lds_base + (unsigned)(OFF + wave * SN_EPI_WAVE_BYTES));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+            ct += G;
+            if (ct < ntiles) consumer_setup();
+        }
+        return remaining > 0;
     };
-    using steady_t = std::integral_constant<bool, true>;
-    using tail_t = std::integral_constant<bool, false>;
     using s0 = std::integral_constant<int, 0>;
     using s1 = std::integral_constant<int, 1>;
     using s2 = std::integral_constant<int, 2>;
-    int k = 0;
-    for (; k + 4 < nsteps; k += 3) {
-        step(steady_t{}, s0{}, k);
-        step(steady_t{}, s1{}, k + 1);
-        step(steady_t{}, s2{}, k + 2);
+    while (true) {
+        if (!step(s0{})) break;
+        if (!step(s1{})) break;
+        if (!step(s2{})) break;
     }
-    // tail: the last 1..4 steps (at most two of them still issue)
-    if (k < nsteps) step(tail_t{}, s0{}, k);
-    if (k + 1 < nsteps) step(tail_t{}, s1{}, k + 1);
-    if (k + 2 < nsteps) step(tail_t{}, s2{}, k + 2);
-    if (k + 3 < nsteps) step(tail_t{}, s0{}, k + 3);
 #undef SN_DS_READ
 #undef SN_LGKM_WAIT
 #undef SN_MFMA4
-    CONV_STAMP_AT(2);
-    __syncthreads();                                       // every wave is done with the last stage
-    conv_epilogue<1, 1>(acc, p, m0 + wm * 32, n0 + wn * 32, lane, tile.z, ring + wave * SN_EPI_WAVE_FLOATS);
-    CONV_STAMP_AT(3);
 }

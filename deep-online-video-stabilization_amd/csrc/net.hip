@@ -468,8 +468,8 @@ const char* stabnet_prof_kind_name(int kind) {
         case PK_KERNEL_WGRAD: return "conv_wgrad_f32_kernel";
         default: break;
     }
-    if (kind == PK_KERNEL_CONV_RING) return "conv_ring_f32_kernel<0, 3>";
-    if (kind == PK_KERNEL_CONV_RING + 1) return "conv_ring_f32_kernel<1, 3>";
+    if (kind == PK_KERNEL_CONV_RING) return "conv_ring_f32_kernel<0>";
+    if (kind == PK_KERNEL_CONV_RING + 1) return "conv_ring_f32_kernel<1>";
     if (kind >= PK_KERNEL_CONV_BASE && kind < PK_KERNEL_CONV_BASE + 18) {
         // names as rocprofv3 prints the template instantiation: <BM, BN, BK, WM, WN, MODE, NBUF>
         static thread_local char buf[96];

@@ -1,7 +1,6 @@
 // Ablation / timeline probe of the LDS-DMA ring conv kernel.
 //   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -DRING_ABLATE=<mask> -I deep-online-video-stabilization_amd/csrc -o /tmp/ring_probe tools/ring_probe.hip
-// mask bits: 1 no DMA, 2 no barrier, 4 no ds_read, 8 no MFMA.   args: H W Cin Cout KH   (stride 1, SAME padding)
-#define CONV_STAMP 1
+// mask bits: 1 no DMA, 2 no barrier, 4 no ds_read, 8 no MFMA.   args: H W Cin Cout KH [workgroups]   (stride 1, SAME padding)
 #include "conv_ring_kernel.h"
 #include <cstdio>
 #include <vector>
@@ -17,15 +16,15 @@ int main(int argc, char** argv) {
     (void)hipMemset(x, 0, (size_t)M * Cin * 4); (void)hipMemset(w, 0, (size_t)N * K * 4);
     a.x = x; a.w = w; a.y = y; a.N = 1; a.H = H; a.W = W; a.Cin = Cin; a.Cout = N; a.KH = KH; a.KW = KH; a.stride = 1; a.pad = KH / 2;
     a.up = 1; a.Ho = H; a.Wo = W; a.res_H = H; a.res_W = W; a.res_stride = 1; a.M = M; a.K = K; a.splitk = 1;
+    sn_fastdiv_make((unsigned)(a.Ho * a.Wo), a.div_hw_mul, a.div_hw_shift); sn_fastdiv_make((unsigned)a.Wo, a.div_w_mul, a.div_w_shift);
     a.steps_per_split = K / 32;
     dim3 grid((M + 63) / 64, (N + 63) / 64, 1);
     const size_t nblk = (size_t)grid.x * grid.y;
-    unsigned long long* stamps;
-    (void)hipMalloc(&stamps, nblk * 4 * 8); (void)hipMemset(stamps, 0, nblk * 4 * 8);
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), &stamps, sizeof(stamps));
+    const int wgs = argc > 6 ? atoi(argv[6]) : 768;
+    const int g1 = (int)std::min<size_t>(nblk, (size_t)wgs);
     auto launch = [&]() {
-        if (KH == 1) conv_ring_f32_kernel<0, 3><<<grid, 256>>>(a);
-        else conv_ring_f32_kernel<1, 3><<<grid, 256>>>(a);
+        if (KH == 1) conv_ring_f32_kernel<0><<<g1, 256>>>(a);
+        else conv_ring_f32_kernel<1><<<g1, 256>>>(a);
     };
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) launch();
@@ -36,12 +35,5 @@ int main(int argc, char** argv) {
     float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 20;
     printf("ABLATE=%2d M=%d K=%d N=%d blocks=%zu (%.2f/CU): %.1f us  %.1f TFLOP/s nominal\n", RING_ABLATE, M, K, N, nblk, nblk / 256.0,
            ms * 1e3, 2.0 * M * K * N / ms / 1e9);
-    std::vector<unsigned long long> h(nblk * 4);
-    (void)hipMemcpy(h.data(), stamps, nblk * 4 * 8, hipMemcpyDeviceToHost);
-    unsigned long long t0 = ~0ull, t3 = 0; double pro = 0, loop = 0, epi = 0, last_start = 0;
-    for (size_t b = 0; b < nblk; ++b) { t0 = std::min(t0, h[b*4]); t3 = std::max(t3, h[b*4+3]); pro += h[b*4+1]-h[b*4]; loop += h[b*4+2]-h[b*4+1]; epi += h[b*4+3]-h[b*4+2]; }
-    for (size_t b = 0; b < nblk; ++b) last_start = std::max(last_start, (double)(h[b*4]-t0));
-    printf("  s_memtime ticks (100 MHz): kernel span %.0f; avg per block: prologue %.0f, loop %.0f, epilogue %.0f; last block starts at +%.0f\n",
-           (double)(t3-t0), pro/nblk, loop/nblk, epi/nblk, last_start);
     return 0;
 }
