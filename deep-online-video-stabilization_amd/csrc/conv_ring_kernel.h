@@ -11,11 +11,11 @@
 //            chunk index, chunk_phys = chunk ^ ((row >> 1) & 7), applied on the SOURCE address of the DMA lane and on
 //            the read address (both sides or neither: the LDS image itself is lane-linear)
 //   DMA    : per stage each wave issues 2 A + 2 B instructions (8 rows each); lane l -> row 8g + (l>>3), chunk l&7
-//   sync   : counted `s_waitcnt vmcnt(4)` (the next stage stays in flight) + ONE raw s_barrier per K-step, which both
-//            publishes stage k and retires every wave's reads of stage k-1 (the slot the new DMA overwrites)
+//   sync   : counted `s_waitcnt vmcnt(4)` (later stages stay in flight) + ONE raw s_barrier per K-step, which both
+//            publishes the next stage and retires every wave's reads of the current one (the slot the new DMA overwrites)
 //   padding: out-of-frame taps read a 16-B zero page (no prologue => zeros stay zeros, nothing to mask afterwards)
 //   persist: the grid is at most 3 workgroups per CU; workgroup b walks tiles b, b+G, b+2G, ... and the ring runs ACROSS
-//            tile boundaries: the producer side (DMA issue) is two K-steps ahead of the consumer side (MFMA), so the
+//            tile boundaries: the producer side (DMA issue) is three K-steps ahead of the consumer side (MFMA), so the
 //            first stages of the next tile are in flight while the current tile's epilogue runs.  The epilogue's
 //            transposition scratch overlays the stage that was consumed last (free until the step after next issues
 //            into it, behind a barrier).
@@ -24,7 +24,7 @@
 #include <type_traits>
 
 #ifndef RING_ABLATE
-#define RING_ABLATE 0          // probe-only bit mask (tools/ring_probe.hip): 1 no DMA, 2 no barrier, 4 no ds_read, 8 no MFMA
+#define RING_ABLATE 0          // probe-only bit mask (tools/ring_probe.hip): 1 no DMA, 2 no barrier, 4 no ds_read, 8 no MFMA, 16 no vmcnt wait
 #endif
 
 typedef __attribute__((address_space(3))) void* sn_lds_ptr_t;
@@ -105,21 +105,23 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         xb = p.x + ((l_kh * p.W + l_kw) * p.Cin + l_c0 - pad_off);
         wb = p.w + (l_tap * p.Cin + l_c0);
     };
-    // issue one stage into `st` (no-op when every tile of this workgroup has been issued)
-    auto issue = [&](float* const st) {
+    // Issue one stage into ring slot `slot` (no-op when every tile of this workgroup has been issued), in four parts so
+    // that the K loop can place each DMA (and its address arithmetic) in the shadow of an MFMA.
+    const unsigned dma_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)wave * 1024u));
+    auto issue_a = [&](int slot, int t) {
+        if (pt >= ntiles || (RING_ABLATE & 1)) return;
+        const float* src = xb + a_voff[t];
+        if (MODE == 1) src = ((a_mask[t] >> l_tap) & 1ull) ? src : zero_page;
+        __builtin_amdgcn_global_load_lds((sn_gbl_ptr_t)src, (sn_lds_ptr_t)(size_t)(dma_base + (unsigned)(slot * STAGE * 4 + t * 4096)),
+                                         16, 0, 0);
+    };
+    auto issue_b = [&](int slot, int t) {
+        if (pt >= ntiles || (RING_ABLATE & 1)) return;
+        __builtin_amdgcn_global_load_lds((sn_gbl_ptr_t)(wb + w_voff[t]),
+                                         (sn_lds_ptr_t)(size_t)(dma_base + (unsigned)(slot * STAGE * 4 + BM * BK * 4 + t * 4096)), 16, 0, 0);
+    };
+    auto issue_advance = [&]() {
         if (pt >= ntiles) return;
-        if (!(RING_ABLATE & 1)) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float* src = xb + a_voff[t];
-                if (MODE == 1) src = ((a_mask[t] >> l_tap) & 1ull) ? src : zero_page;
-                __builtin_amdgcn_global_load_lds((sn_gbl_ptr_t)src, (sn_lds_ptr_t)(st + (wave + 4 * t) * 256), 16, 0, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                __builtin_amdgcn_global_load_lds((sn_gbl_ptr_t)(wb + w_voff[t]),
-                                                 (sn_lds_ptr_t)(st + BM * BK + (wave + 4 * t) * 256), 16, 0, 0);
-        }
         if (--p_left == 0) {
             pt += G;
             if (pt < ntiles) producer_setup();
@@ -133,6 +135,10 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
             ++l_tap;
             if (++l_kw == p.KW) { l_kw = 0; xb += row_jump; }
         }
+    };
+    auto issue = [&](int slot) {
+        issue_a(slot, 0); issue_a(slot, 1); issue_b(slot, 0); issue_b(slot, 1);
+        issue_advance();
     };
 
     // ---- consumer state: the tile being accumulated
@@ -165,73 +171,115 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     if (remaining == 0) return;                            // (the grid never exceeds the tile count; kept for safety)
     producer_setup();
     consumer_setup();
-    issue(ring);                                           // two stages in flight
-    issue(ring + STAGE);
 
     // The fragment reads are inline asm on purpose: the compiler's waitcnt insertion cannot tell which DMA a ds_read
-    // depends on and puts `s_waitcnt vmcnt(0)` in front of compiler-visible LDS loads, draining the stage that was just
-    // put in flight.  Waits are therefore explicit: vmcnt before the barrier, lgkmcnt (tied to the fragment registers
-    // through "+v" so the MFMAs cannot move above them) before each MFMA group.
-#define SN_DS_READ(dst, addr, off)                                                                        \
-    do { if (!(RING_ABLATE & 4)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off)); } while (0)
-#define SN_LGKM_WAIT(n, a, b) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b))
-#define SN_MFMA4(a, b)                                                                        \
-    if (!(RING_ABLATE & 8)) {                                                                 \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);       \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[0][0], 0, 0, 0);       \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[0][0], 0, 0, 0);       \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[0][0], 0, 0, 0);       \
-    } else {                                                                                  \
-        acc[0][0][0] += a.x * b.x;                                                            \
-    }
+    // depends on and puts `s_waitcnt vmcnt(0)` in front of compiler-visible LDS loads, draining the stages in flight.
+    // Waits are therefore explicit: vmcnt before the barrier, lgkmcnt (tied to the fragment registers through "+v" so the
+    // MFMAs cannot move above them) before each MFMA group.
+    // Between a read and its wait the compiler believes the destination already holds the data; a register copy there
+    // would copy stale contents.  The fragment variables are therefore bound to FIXED physical registers at every asm
+    // boundary (no phi copies at the loop back-edge or around the epilogue branch), and the one place where a fragment
+    // pair stays in flight across a long code region (the epilogue) waits for it first.
+#define SN_RA0 "{v[100:103]}"
+#define SN_RB0 "{v[104:107]}"
+#define SN_RA1 "{v[108:111]}"
+#define SN_RB1 "{v[112:115]}"
+#define SN_DS_READ(dst, reg, addr, off)                                                                   \
+    do { if (!(RING_ABLATE & 4)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=" reg(dst) : "v"(addr), "n"(off)); } while (0)
+#define SN_READ0(kk, off) do { SN_DS_READ(a0, SN_RA0, a_frag[kk], off); SN_DS_READ(b0, SN_RB0, b_frag[kk], off); } while (0)
+#define SN_READ1(kk, off) do { SN_DS_READ(a1, SN_RA1, a_frag[kk], off); SN_DS_READ(b1, SN_RB1, b_frag[kk], off); } while (0)
+#define SN_WAIT0() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA0(a0), "+" SN_RB0(b0))
+#define SN_WAIT1() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA1(a1), "+" SN_RB1(b1))
+#define SN_MFMA1(a, b, c)                                                                                      \
+    do {                                                                                                       \
+        if (!(RING_ABLATE & 8)) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.c, b.c, acc[0][0], 0, 0, 0); \
+        else acc[0][0][0] += a.c * b.c;                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    } while (0)
+#define SN_BARRIER()                                                     \
+    do {                                                                 \
+        if (!(RING_ABLATE & 2)) __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);                               \
+    } while (0)
+
+    // Schedule.  Stage s lives in slot s % 3; the producer runs THREE stages ahead of the MFMAs.  An MFMA occupies the
+    // matrix pipe for 64 cycles but a wave issues in order, so anything placed AFTER a group of MFMAs is only covered by
+    // the last one: every non-MFMA instruction of the loop is therefore placed right after ONE MFMA (sched_barrier pins
+    // the order): the two ds_read_b128 of the next fragment pair after the first MFMA of each group, the four DMAs of
+    // stage k+3 after the last three MFMAs of the step.  Entering step k the kk = 0 fragments of stage k are in flight
+    // to (a0, b0).  The step's barrier sits inside its LAST MFMA group: by then every fragment of stage k is in
+    // registers, so the barrier (a) publishes stage k+1, (b) frees slot k % 3 for stage k+3.  At a tile's last step the
+    // freed slot first serves as the epilogue's transposition scratch; stage k+3 is issued after it, behind one more barrier.
+    f32x4 a0, b0, a1, b1;
+    if (RING_ABLATE & 4) { a0 = b0 = a1 = b1 = f32x4{1.f, 2.f, 3.f, 4.f}; }
+    issue(0);
+    issue(1);
+    if (remaining > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SN_BARRIER();
+    issue(2);
+    SN_READ0(0, 0);
 
     // One K-step on ring slot SLOT; returns false after the workgroup's last step.
     auto step = [&](auto slot_c) -> bool {
         constexpr int SLOT = decltype(slot_c)::value;
-        constexpr int ISSUE_SLOT = (SLOT + 2) % 3;
         constexpr int OFF = SLOT * STAGE * 4;
-        // This stage has landed for THIS wave when at most the next stage's 4 DMAs are outstanding.  (Epilogue stores of
-        // the previous tile may still be in flight behind them: the counter retires in order, so the wait is then
-        // stricter than needed, never weaker.)
-        if (remaining > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(RING_ABLATE & 2)) __builtin_amdgcn_s_barrier();   // stage complete for all waves; previous slot no longer read
-        __builtin_amdgcn_sched_barrier(0);
-        issue(ring + ISSUE_SLOT * STAGE);                       // overwrites the slot consumed by the previous step
-        f32x4 a0, b0, a1, b1;
-        if (RING_ABLATE & 4) { a0 = b0 = a1 = b1 = f32x4{1.f, 2.f, 3.f, 4.f}; }
-        SN_DS_READ(a0, a_frag[0], OFF);
-        SN_DS_READ(b0, b_frag[0], OFF);
-        SN_DS_READ(a1, a_frag[1], OFF);
-        SN_DS_READ(b1, b_frag[1], OFF);
-        SN_LGKM_WAIT(2, a0, b0);
-        SN_MFMA4(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        SN_DS_READ(a0, a_frag[2], OFF);
-        SN_DS_READ(b0, b_frag[2], OFF);
-        SN_LGKM_WAIT(2, a1, b1);
-        SN_MFMA4(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        SN_DS_READ(a1, a_frag[3], OFF);
-        SN_DS_READ(b1, b_frag[3], OFF);
-        SN_LGKM_WAIT(2, a0, b0);
-        SN_MFMA4(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        SN_LGKM_WAIT(0, a1, b1);
-        SN_MFMA4(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
+        constexpr int OFF_NEXT = ((SLOT + 1) % 3) * STAGE * 4;
+        SN_WAIT0();
+        SN_MFMA1(a0, b0, x);
+        SN_READ1(1, OFF);
+        SN_MFMA1(a0, b0, y);
+        SN_MFMA1(a0, b0, z);
+        SN_MFMA1(a0, b0, w);
+        SN_WAIT1();
+        SN_MFMA1(a1, b1, x);
+        SN_READ0(2, OFF);
+        SN_MFMA1(a1, b1, y);
+        SN_MFMA1(a1, b1, z);
+        SN_MFMA1(a1, b1, w);
+        SN_WAIT0();
+        SN_MFMA1(a0, b0, x);
+        SN_READ1(3, OFF);
+        SN_MFMA1(a0, b0, y);
+        SN_MFMA1(a0, b0, z);
+        SN_MFMA1(a0, b0, w);
+        SN_WAIT1();                                        // every fragment of this stage is in registers
+        SN_MFMA1(a1, b1, x);
         --remaining;
-        if (--c_left == 0) {
-            __builtin_amdgcn_s_barrier();                  // every wave is done reading slot SLOT: it becomes the scratch
-            __builtin_amdgcn_sched_barrier(0);             // (raw barrier: __syncthreads() would also drain the DMA queue)
+        const bool tile_done = (--c_left == 0);
+        const bool more = remaining > 0, feed = more && !tile_done;
+        if (more) {
+            // stage k+1 has landed for THIS wave when at most stage k+2's 4 DMAs are outstanding.  (Epilogue stores of
+            // an earlier tile may be in flight too: the counter retires in order, so the wait is then stricter, never weaker.)
+            if (!(RING_ABLATE & 16)) {
+                if (remaining > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            SN_BARRIER();
+            SN_READ0(0, OFF_NEXT);
+        }
+        if (feed) { issue_a(SLOT, 0); __builtin_amdgcn_sched_barrier(0); }     // stage k+3 into the slot just retired
+        SN_MFMA1(a1, b1, y);
+        if (feed) { issue_a(SLOT, 1); issue_b(SLOT, 0); __builtin_amdgcn_sched_barrier(0); }
+        SN_MFMA1(a1, b1, z);
+        if (feed) { issue_b(SLOT, 1); __builtin_amdgcn_sched_barrier(0); }
+        SN_MFMA1(a1, b1, w);
+        if (feed) { issue_advance(); __builtin_amdgcn_sched_barrier(0); }
+        if (tile_done) {
+            if (more) SN_WAIT0();                          // the next tile's first fragments: landed before the epilogue code
+            else SN_BARRIER();                             // (otherwise the barrier above already retired slot SLOT)
             conv_epilogue<1, 1>(acc, p, c_m0 + wm * 32, c_n0 + wn * 32, lane, c_z,
                                 lds_base + (unsigned)(OFF + wave * SN_EPI_WAVE_BYTES));
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
             ct += G;
             if (ct < ntiles) consumer_setup();
+            if (more) {
+                SN_BARRIER();                              // every wave is done with the scratch
+                issue(SLOT);
+            }
         }
-        return remaining > 0;
+        return more;
     };
     using s0 = std::integral_constant<int, 0>;
     using s1 = std::integral_constant<int, 1>;
@@ -241,7 +289,11 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         if (!step(s1{})) break;
         if (!step(s2{})) break;
     }
+#undef SN_BARRIER
 #undef SN_DS_READ
-#undef SN_LGKM_WAIT
-#undef SN_MFMA4
+#undef SN_READ0
+#undef SN_READ1
+#undef SN_WAIT0
+#undef SN_WAIT1
+#undef SN_MFMA1
 }
