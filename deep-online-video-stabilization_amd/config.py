@@ -40,6 +40,11 @@ class Config:
     grid_h: int = 4
     grid_w: int = 4
     grid_theta_mul: float = 0
+    random_crop_rate: float = 0.9
+    max_crop_rate: float = 0.6
+    rand_H_max: tuple = ((1.1, 0.1, 0.5), (0.1, 1.1, 0.5), (0.1, 0.1, 1.0))
+    rand_H_min: tuple = ((0.9, -0.1, -0.5), (-0.1, 0.9, -0.5), (-0.1, -0.1, 1.0))
+    rand_H_change_rate: float = 1
     weight_decay_fc: float = 0.0002
     weight_decay_conv: float = 0.0001
     bn_eps: float = 1e-5

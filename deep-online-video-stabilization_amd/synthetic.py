@@ -149,3 +149,33 @@ def make_train_batch(cfg: Config, N: int, H: int, W: int, seed: int = 1234):
         m[:, :500] = 1
         out["mask" + k] = m
     return out
+
+
+def make_raw_pairs(cfg: Config, N: int, H: int, W: int, seed: int = 1234):
+    """Un-augmented pair material in the layout read_and_decode assembles before its random ops
+    (get_data_mini_after.py:177-213): stable [N,H,W,2*(before_ch+1)] = (label, before_ch history frames) of tower 1 then
+    tower 2, unstable [N,H,W,2] current frames, flow [N,H,W,2], matches [N,max_matches,4] zero-padded + valid counts.
+    Feed to stabnet_amd.data.augment_pairs."""
+    rng = np.random.default_rng(seed + 11)
+    bc = cfg.before_ch
+    stable = np.empty((N, H, W, 2 * (bc + 1)), np.float32)
+    unstable = np.empty((N, H, W, 2), np.float32)
+    for n in range(N):
+        st = make_clip(H, W, bc + 2, seed=seed * 1000 + n, margin=32)            # smooth camera path
+        sh = make_clip(H, W, 2, seed=seed * 1000 + n + 500, margin=32)            # the shaky views of the two current frames
+        for tower in range(2):
+            stable[n, :, :, tower * (bc + 1)] = st[bc + tower]                     # label = stable frame at the current time
+            for k in range(bc):
+                stable[n, :, :, tower * (bc + 1) + 1 + k] = st[max(bc - 1 - k + tower, 0)]
+            unstable[n, :, :, tower] = sh[tower]
+    gx, gy = np.meshgrid(np.linspace(-1, 1, W, dtype=np.float32), np.linspace(-1, 1, H, dtype=np.float32))
+    flow = (np.stack([gx, gy], axis=2)[None].repeat(N, 0) + rng.normal(0, 0.01, (N, H, W, 2))).astype(np.float32)
+    out = {"stable": stable, "unstable": unstable, "flow": flow}
+    for k in ("1", "2"):
+        cnt = rng.integers(400, 600, N).astype(np.int32)
+        m = rng.uniform(-1, 1, (N, cfg.max_matches, 4)).astype(np.float32)
+        for n in range(N):
+            m[n, cnt[n]:] = 0
+        out["matches" + k] = m
+        out["n" + k] = cnt
+    return out

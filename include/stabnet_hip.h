@@ -243,6 +243,22 @@ size_t stabnet_crop_search_workspace_bytes(int H, int W, int step);
 int stabnet_crop_search(const int* all_black, int H, int W, int step, int* ans5, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/* ---- next to the path: training sample assembly -------------------------------------
+ * read_and_decode's tensor part (get_data_mini_after.py:229-253) for N pairs at once: warp_img (:14-31: bilinear up-scale
+ * by 1/random_crop_rate, crop, flip, tf.image contrast + brightness, clip) on the 2*(before_ch+1) stable and 2 unstable
+ * channels, add_mask (:93-147: random-homography black masks, masked pixels = -1), warp_flow (:33-51), warp_point
+ * (:53-70).  The random draws are INPUTS (device arrays): para [N][3] = crop row, crop column, flip; jitter [N][2] =
+ * contrast factor, brightness delta; Hs [N][2][before_ch][9] mask homographies (tower, channel).
+ * stable [N,H,W,2*(before_ch+1)] (label, history x before_ch, per tower), unstable [N,H,W,2], flow [N,H,W,2] (or NULL),
+ * matches [N,max_matches,4] + n [N] valid counts (or NULL).  Outputs NHWC: x1,x2 [N,H,W,2*before_ch+1] (masks, masked
+ * history, current), y1,y2 [N,H,W,1], flow_out, fm [N,max_matches,4], mk [N,max_matches] (0/1 floats). */
+size_t stabnet_augment_workspace_bytes(int N, int H, int W, int before_ch);
+int stabnet_augment_pairs(const float* stable, const float* unstable, const float* flow_in, const float* matches1,
+                          const int* n1, const float* matches2, const int* n2, const int* para, const float* jitter,
+                          const float* Hs, int N, int H, int W, int before_ch, int max_matches, float random_crop_rate,
+                          float* x1, float* y1, float* x2, float* y2, float* flow_out, float* fm1, float* mk1, float* fm2,
+                          float* mk2, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

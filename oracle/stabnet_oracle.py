@@ -734,3 +734,119 @@ def max_inscribed_rect(all_black, step=10):
                 if s > max_s:                   # within one hh the area grows with ww: the last free column is the max
                     max_s, ans = s, [i, j, hh, j + n_free - 1]
     return ans, max_s
+
+
+# --------------------------------------------------------------------------- training sample assembly (SURVEY 8f rank 3)
+# get_data_mini_after.py:7-147,229-253.  The reference draws its random numbers inside the TF graph (Philox streams that
+# cannot be reproduced without TF); here every random quantity is an INPUT (crop offsets, flip, the contrast factor and
+# brightness delta, the mask homographies), so the arithmetic after the draw is what is restated and compared.
+RANDOM_CROP_RATE = 0.9                      # configs/v2_93.py:23
+RAND_H_MAX = np.array([[1.1, 0.1, 0.5], [0.1, 1.1, 0.5], [0.1, 0.1, 1]], np.float32)      # configs/v2_93.py:37
+RAND_H_MIN = np.array([[0.9, -0.1, -0.5], [-0.1, 0.9, -0.5], [-0.1, -0.1, 1]], np.float32)  # configs/v2_93.py:38
+
+
+def tf_resize_bilinear(img, oh, ow):
+    """[external] tf.image.resize_images(BILINEAR) of TF 1.3 = ResizeBilinear(align_corners=False): scale = in/out (float32),
+    in = out_index * scale, top = floor, bottom = min(ceil, in-1), lerp = in - top;
+    out = top_row + (bottom_row - top_row) * y_lerp with row values tl + (tr - tl) * x_lerp.  img [H,W] float32."""
+    img = np.asarray(img, F)
+    ih, iw = img.shape
+    hs, ws = F(ih) / F(oh), F(iw) / F(ow)
+    iy = (np.arange(oh, dtype=F) * hs).astype(F)
+    ix = (np.arange(ow, dtype=F) * ws).astype(F)
+    y0 = np.floor(iy).astype(np.int64); y1 = np.minimum(np.ceil(iy).astype(np.int64), ih - 1); ly = (iy - y0.astype(F)).astype(F)
+    x0 = np.floor(ix).astype(np.int64); x1 = np.minimum(np.ceil(ix).astype(np.int64), iw - 1); lx = (ix - x0.astype(F)).astype(F)
+    tl, tr = img[y0][:, x0], img[y0][:, x1]
+    bl, br = img[y1][:, x0], img[y1][:, x1]
+    top = (tl + ((tr - tl).astype(F) * lx[None, :]).astype(F)).astype(F)
+    bot = (bl + ((br - bl).astype(F) * lx[None, :]).astype(F)).astype(F)
+    return (top + ((bot - top).astype(F) * ly[:, None]).astype(F)).astype(F)
+
+
+def aug_resized_hw(H, W, rate=RANDOM_CROP_RATE):
+    return int(H / rate), int(W / rate)         # get_data_mini_after.py:8-9
+
+
+def warp_img(image, para, contrast, brightness, rate=RANDOM_CROP_RATE):
+    """get_data_mini_after.py:14-31 for one [H,W] channel: resize up, crop at (para h, w), flip, tf.image contrast
+    ((x - mean)*factor + mean, per-channel mean over H,W) and brightness (x + delta), clip to [-0.5, 0.5]."""
+    H, W = image.shape
+    h, w = aug_resized_hw(H, W, rate)
+    big = tf_resize_bilinear(image, h, w)
+    img = big[para["h"]:para["h"] + H, para["w"]:para["w"] + W]
+    if para["flip"]:
+        img = img[:, ::-1]
+    mean = F(np.asarray(img, np.float64).mean())
+    img = (((img - mean).astype(F) * F(contrast)).astype(F) + mean).astype(F)
+    img = (img + F(brightness)).astype(F)
+    return np.clip(img, F(-0.5), F(0.5)).astype(F)
+
+
+def warp_flow(flow, para, rate=RANDOM_CROP_RATE):
+    """get_data_mini_after.py:33-51.  flow [H,W,2] in normalised coordinates."""
+    H, W = flow.shape[:2]
+    h, w = aug_resized_hw(H, W, rate)
+    fx = tf_resize_bilinear(flow[..., 0], h, w)[para["h"]:para["h"] + H, para["w"]:para["w"] + W]
+    fy = tf_resize_bilinear(flow[..., 1], h, w)[para["h"]:para["h"] + H, para["w"]:para["w"] + W]
+    ox = F(1) - (F(para["w"]) / F(w)) * F(2)
+    oy = F(1) - (F(para["h"]) / F(h)) * F(2)
+    fx = (((fx + ox).astype(F) / F(H / float(h))).astype(F) - F(1)).astype(F)     # (sic) x is divided by height/h
+    fy = (((fy + oy).astype(F) / F(W / float(w))).astype(F) - F(1)).astype(F)
+    if para["flip"]:
+        fy = fy[:, ::-1]
+        fx = ((fx[:, ::-1] * F(-1)).astype(F) - F(1.0 / W)).astype(F)
+    return np.stack([fx, fy], axis=2).astype(F)
+
+
+def warp_point(points, mask, para, H, W, rate=RANDOM_CROP_RATE):
+    """get_data_mini_after.py:53-70.  points [M,4] = (x1,y1,x2,y2) normalised; mask [M] bool."""
+    h, w = aug_resized_hw(H, W, rate)
+    p = np.asarray(points, F)
+    ox = F(1) - (F(para["w"]) / F(w)) * F(2)
+    oy = F(1) - (F(para["h"]) / F(h)) * F(2)
+    px = (((p[:, [0, 2]] + ox).astype(F) / F(H / float(h))).astype(F) - F(1)).astype(F)
+    py = (((p[:, [1, 3]] + oy).astype(F) / F(W / float(w))).astype(F) - F(1)).astype(F)
+    if para["flip"]:
+        px = ((px * F(-1)).astype(F) - F(1.0 / W)).astype(F)
+    out = np.stack([px[:, 0], py[:, 0], px[:, 1], py[:, 1]], axis=1).astype(F)
+    ok = np.logical_and(np.all(np.logical_and(out >= -1, out <= 1), axis=1), np.asarray(mask, bool))
+    return out, ok
+
+
+def rand_mask_from_H(Hm, H, W):
+    """get_data_mini_after.py:93-108: black where H*grid leaves [-1,1] (strict), grid = (linspace x, linspace y, 1)."""
+    Hm = np.asarray(Hm, F)
+    gx = linspace_tf(-1.0, 1.0, W)[None, :].repeat(H, 0)
+    gy = linspace_tf(-1.0, 1.0, H)[:, None].repeat(W, 1)
+
+    def row(r):      # tf.matmul [3,3]x[3,HW]: one dot product of length 3 per element, accumulated in order
+        return ((Hm[r, 0] * gx).astype(F) + (Hm[r, 1] * gy).astype(F) + Hm[r, 2]).astype(F)
+    xs, ys, zs = row(0), row(1), row(2)
+    x = (xs / zs).astype(F); y = (ys / zs).astype(F)
+    return ((F(-1) > x) | (x > F(1)) | (F(-1) > y) | (y > F(1))).astype(F)
+
+
+def add_mask(pics, Hs, input_mask=True):
+    """get_data_mini_after.py:128-147.  pics [H,W,before_ch]; Hs [before_ch,3,3] (rand_H_change_rate = 1: every channel a
+    fresh homography).  Returns [H,W,2*before_ch] = masks then masked frames (masked pixels = -1)."""
+    H, W, C = pics.shape
+    masks = np.stack([rand_mask_from_H(Hs[i], H, W) for i in range(C)], axis=2)
+    ans = ((pics * (F(1) - masks)).astype(F) + (masks * F(-1)).astype(F)).astype(F)
+    return np.concatenate([masks, ans], axis=2) if input_mask else ans
+
+
+def assemble_pair(stable, unstable, flow, matches1, n1, matches2, n2, para, contrast, brightness, Hs1, Hs2, cfg: Config):
+    """get_data_mini_after.py:229-253.  stable [H,W,2*(before_ch+1)] (y1, 6 history, y2, 6 history), unstable [H,W,2]."""
+    bc = cfg.before_ch
+    H, W = stable.shape[:2]
+    st = np.stack([warp_img(stable[..., i], para, contrast, brightness) for i in range(stable.shape[2])], axis=2)
+    un = np.stack([warp_img(unstable[..., i], para, contrast, brightness) for i in range(unstable.shape[2])], axis=2)
+    x1 = np.concatenate([add_mask(st[..., 1:1 + bc], Hs1, cfg.input_mask), un[..., 0:1]], axis=2)
+    y1 = st[..., 0:1]
+    x2 = np.concatenate([add_mask(st[..., bc + 2:2 * bc + 2], Hs2, cfg.input_mask), un[..., 1:2]], axis=2)
+    y2 = st[..., bc + 1:bc + 2]
+    m1 = np.arange(cfg.max_matches) < n1
+    m2 = np.arange(cfg.max_matches) < n2
+    fm1, mk1 = warp_point(matches1, m1, para, H, W)
+    fm2, mk2 = warp_point(matches2, m2, para, H, W)
+    return x1, y1, x2, y2, warp_flow(flow, para), fm1, mk1, fm2, mk2

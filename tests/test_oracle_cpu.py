@@ -225,3 +225,26 @@ def test_crop_search_restatement_equals_the_literal_reference_loop():
         m = (rng.random((H, W)) < dens).astype(np.int64)
         for step in (3, 10):
             assert literal(m, step) == O.max_inscribed_rect(m, step), (t, step)
+
+
+def test_sample_assembly_known_answers():
+    """KATs of the sample-assembly restatement (get_data_mini_after.py): resize at scale 1 is the identity; the identity
+    homography blacks nothing and a translation by +2 in x blacks everything; contrast 1 / brightness 0 / no flip / zero
+    crop offsets reproduce the top-left crop of the up-scaled frame; flipping twice is the identity on points."""
+    rng = np.random.default_rng(3)
+    img = rng.uniform(-0.5, 0.5, (18, 32)).astype(np.float32)
+    assert np.array_equal(O.tf_resize_bilinear(img, 18, 32), img)
+    up = O.tf_resize_bilinear(img, 36, 64)
+    assert np.array_equal(up[::2, ::2], img)                                   # scale 1/2: even samples hit source pixels
+    eye = np.eye(3, dtype=np.float32)
+    assert O.rand_mask_from_H(eye, 18, 32).sum() == 0
+    shift = eye.copy(); shift[0, 2] = 2.5
+    assert O.rand_mask_from_H(shift, 18, 32).sum() == 18 * 32
+    h, w = O.aug_resized_hw(18, 32)
+    out = O.warp_img(img, {"h": 0, "w": 0, "flip": 0}, 1.0, 0.0)
+    ref = O.tf_resize_bilinear(img, h, w)[:18, :32]
+    assert np.abs(out - np.clip(ref, -0.5, 0.5)).max() <= 6e-8                 # (x-mean)*1+mean rounds once more
+    pts = rng.uniform(-0.8, 0.8, (5, 4)).astype(np.float32)
+    p0, _ = O.warp_point(pts, np.ones(5, bool), {"h": 0, "w": 0, "flip": 0}, 18, 32)
+    p1, _ = O.warp_point(pts, np.ones(5, bool), {"h": 0, "w": 0, "flip": 1}, 18, 32)
+    assert np.allclose(p1[:, [0, 2]], -p0[:, [0, 2]] - 1.0 / 32, atol=1e-6) and np.array_equal(p1[:, [1, 3]], p0[:, [1, 3]])

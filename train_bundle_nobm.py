@@ -31,6 +31,9 @@ def build_parser():
     p.add_argument('--width', type=int, default=None)
     p.add_argument('--model-dir', default=None)
     p.add_argument('--disp-freq', type=int, default=None)
+    p.add_argument('--augment', action='store_true',
+                   help='assemble every batch on the device from un-augmented pair material with the reference\'s random '
+                        'crop / flip / contrast / brightness / homography masks (get_data_mini_after.py)')
     return p
 
 
@@ -73,6 +76,15 @@ def main():
 
     def batch_for(step, split):
         seed = (1234 if split == 'train' else 987654) + step * world + rank       # every rank its own shard
+        if args.augment:
+            from stabnet_amd import data
+            raw = synthetic.make_raw_pairs(cfg, N, H, W, seed)
+            para, jitter, Hs = data.draw(np.random.default_rng(seed), cfg, N, H, W)
+            t = lambda k: torch.from_numpy(raw[k]).to(dev)
+            x1, y1, x2, y2, flow, fm1, mk1, fm2, mk2 = data.augment_pairs(
+                t('stable'), t('unstable'), t('flow'), t('matches1'), raw['n1'], t('matches2'), raw['n2'], para, jitter, Hs, cfg)
+            return {'x1': x1, 'y1': y1, 'x2': x2, 'y2': y2, 'flow': flow, 'matches1': fm1, 'mask1': mk1, 'matches2': fm2,
+                    'mask2': mk2}
         b = synthetic.make_train_batch(cfg, N, H, W, seed)
         return {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
 
