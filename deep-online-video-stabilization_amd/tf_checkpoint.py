@@ -1,0 +1,275 @@
+"""TensorFlow checkpoint (V2 "tensor bundle") reader / writer without TensorFlow (first half).
+
+The reference restores `models/v2_93/model-80000` through `tf.train.Saver` (deploy_bundle.py:45-47) and initialises training
+from `data_video/resnet_v2_50.ckpt` (train_bundle_nobm.py:184-191).  Neither TF nor any checkpoint exists in the build image, so
+this module restates the PUBLISHED on-disk format from its specification and is pinned only by its own round trip
+(`tests/test_tf_checkpoint_cpu.py`) -- parity against a checkpoint written by real TF is UNPINNED and said so here:
+
+  <prefix>.index                 a leveldb-format sorted string table (table/format.cc): data blocks of prefix-compressed
+                                 (shared, non_shared, value_len) entries + restart array, an index block, a 48-byte footer
+                                 with magic 0xdb4775248b80fb57.  Key "" -> BundleHeaderProto, key <variable name> ->
+                                 BundleEntryProto {1: dtype, 2: TensorShapeProto, 3: shard_id, 4: offset, 5: size, 6: crc32c}
+  <prefix>.data-00000-of-00001   raw little-endian tensor bytes at [offset, offset + size)
+
+Only what the path needs is supported: uncompressed blocks (BundleWriter writes them uncompressed), one shard or several,
+no sliced (partitioned) variables; dtypes float32/float64/int32/int64.  Anything else raises with a clear message.
+"""
+from __future__ import annotations
+
+import os
+import struct
+
+import numpy as np
+
+_MAGIC = 0xDB4775248B80FB57
+_DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64}          # tensorflow/core/framework/types.proto
+_DTYPE_IDS = {np.dtype(v): k for k, v in _DTYPES.items()}
+
+
+# ------------------------------------------------------------------------------------------------ varints / protobuf wire
+def _get_varint(buf, pos):
+    out = shift = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        out |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return out, pos
+        shift += 7
+
+
+def _put_varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _parse_proto(buf):
+    """-> {field: [values]}; varint fields as int, fixed32 as int, length-delimited as bytes."""
+    out, pos = {}, 0
+    while pos < len(buf):
+        key, pos = _get_varint(buf, pos)
+        field, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _get_varint(buf, pos)
+        elif wt == 1:
+            v = struct.unpack_from("<Q", buf, pos)[0]; pos += 8
+        elif wt == 2:
+            n, pos = _get_varint(buf, pos)
+            v = bytes(buf[pos:pos + n]); pos += n
+        elif wt == 5:
+            v = struct.unpack_from("<I", buf, pos)[0]; pos += 4
+        else:
+            raise ValueError("tf_checkpoint: unsupported protobuf wire type %d" % wt)
+        out.setdefault(field, []).append(v)
+    return out
+
+
+def _signed64(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+# ------------------------------------------------------------------------------------------------ crc32c (Castagnoli)
+_CRC_TABLE = None
+
+
+def _crc_table():
+    global _CRC_TABLE
+    if _CRC_TABLE is None:
+        t = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+            t.append(c)
+        _CRC_TABLE = t
+    return _CRC_TABLE
+
+
+def crc32c(data: bytes, crc: int = 0) -> int:
+    t = _crc_table()
+    c = crc ^ 0xFFFFFFFF
+    for b in data:
+        c = t[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def _mask_crc(c):                       # leveldb / TF crc32c::Mask
+    return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------ table reader
+def _read_block(buf, offset, size):
+    ctype = buf[offset + size]
+    if ctype != 0:
+        raise ValueError("tf_checkpoint: compressed table block (type %d); only uncompressed bundles are supported" % ctype)
+    blk = buf[offset:offset + size]
+    nrestart = struct.unpack_from("<I", blk, len(blk) - 4)[0]
+    end = len(blk) - 4 - 4 * nrestart
+    pos, key, out = 0, b"", []
+    while pos < end:
+        shared, pos = _get_varint(blk, pos)
+        non_shared, pos = _get_varint(blk, pos)
+        vlen, pos = _get_varint(blk, pos)
+        key = key[:shared] + bytes(blk[pos:pos + non_shared]); pos += non_shared
+        out.append((key, bytes(blk[pos:pos + vlen]))); pos += vlen
+    return out
+
+
+def _read_table(path):
+    buf = open(path, "rb").read()
+    if len(buf) < 48 or struct.unpack_from("<Q", buf, len(buf) - 8)[0] != _MAGIC:
+        raise ValueError("tf_checkpoint: %s is not a tensor-bundle index (bad magic)" % path)
+    footer = buf[len(buf) - 48:]
+    _, p = _get_varint(footer, 0); _, p = _get_varint(footer, p)             # metaindex handle (unused)
+    ioff, p = _get_varint(footer, p); isize, p = _get_varint(footer, p)
+    entries = []
+    for _, handle in _read_block(buf, ioff, isize):
+        off, q = _get_varint(handle, 0)
+        size, q = _get_varint(handle, q)
+        entries.extend(_read_block(buf, off, size))
+    return entries
+
+
+def read_bundle(prefix: str, verify_crc_below: int = 1 << 20) -> dict:
+    """All variables of the checkpoint `<prefix>` as {name: ndarray}.  Tensor CRCs are verified for tensors smaller than
+    `verify_crc_below` bytes (the pure-Python CRC is slow; pass a large value to verify everything)."""
+    index = prefix + ".index"
+    if not os.path.exists(index):
+        raise FileNotFoundError(index)
+    entries = _read_table(index)
+    if not entries or entries[0][0] != b"":
+        raise ValueError("tf_checkpoint: missing bundle header")
+    header = _parse_proto(entries[0][1])
+    num_shards = header.get(1, [1])[0]
+    if header.get(2, [0])[0] != 0:
+        raise ValueError("tf_checkpoint: big-endian bundle")
+    shards = {}
+    out = {}
+    for key, val in entries[1:]:
+        e = _parse_proto(val)
+        if 7 in e:
+            raise ValueError("tf_checkpoint: variable %r is sliced (partitioned variables are not supported)" % key.decode())
+        dt = e.get(1, [0])[0]
+        if dt not in _DTYPES:
+            raise ValueError("tf_checkpoint: variable %r has unsupported dtype id %d" % (key.decode(), dt))
+        dims = []
+        if 2 in e:
+            for d in _parse_proto(e[2][0]).get(2, []):
+                dims.append(_signed64(_parse_proto(d).get(1, [0])[0]))
+        shard = e.get(3, [0])[0]
+        off, size = e.get(4, [0])[0], e.get(5, [0])[0]
+        if shard not in shards:
+            shards[shard] = np.memmap("%s.data-%05d-of-%05d" % (prefix, shard, num_shards), dtype=np.uint8, mode="r")
+        raw = shards[shard][off:off + size]
+        if len(raw) != size:
+            raise ValueError("tf_checkpoint: data shard truncated at %r" % key.decode())
+        if size < verify_crc_below and 6 in e:
+            if _mask_crc(crc32c(bytes(raw))) != e[6][0]:
+                raise ValueError("tf_checkpoint: crc mismatch in %r" % key.decode())
+        arr = np.frombuffer(bytes(raw), dtype=_DTYPES[dt])
+        out[key.decode()] = arr.reshape(dims) if dims else arr.reshape(())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ table writer
+def _build_block(items, restart_interval=16):
+    out, restarts, last = bytearray(), [], b""
+    for i, (k, v) in enumerate(items):
+        if i % restart_interval == 0:
+            restarts.append(len(out)); shared = 0
+        else:
+            shared = 0
+            while shared < min(len(last), len(k)) and last[shared] == k[shared]:
+                shared += 1
+        out += _put_varint(shared) + _put_varint(len(k) - shared) + _put_varint(len(v)) + k[shared:] + v
+        last = k
+    for r in restarts or [0]:
+        out += struct.pack("<I", r)
+    out += struct.pack("<I", max(len(restarts), 1))
+    return bytes(out)
+
+
+def _emit_block(f, contents):
+    off = f.tell()
+    f.write(contents)
+    f.write(b"\x00")
+    f.write(struct.pack("<I", _mask_crc(crc32c(b"\x00", crc32c(contents)))))
+    return off, len(contents)
+
+
+def _field(num, wt, payload):
+    return _put_varint((num << 3) | wt) + payload
+
+
+def write_bundle(prefix: str, variables: dict, block_size: int = 4096):
+    """Writes {name: ndarray} as a single-shard V2 checkpoint `<prefix>.index` + `<prefix>.data-00000-of-00001`."""
+    os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
+    items = [(b"", _field(1, 0, _put_varint(1)) + _field(3, 2, _put_varint(2) + _field(1, 0, _put_varint(1))))]   # num_shards=1, version.producer=1
+    with open(prefix + ".data-00000-of-00001", "wb") as data:
+        for name in sorted(variables, key=lambda s: s.encode()):
+            a = np.asarray(variables[name])
+            a = a if a.flags.c_contiguous else a.copy()          # (ascontiguousarray would promote scalars to 1-D)
+            if a.dtype not in _DTYPE_IDS:
+                raise ValueError("tf_checkpoint: dtype %s of %r is not supported" % (a.dtype, name))
+            raw = a.astype(a.dtype.newbyteorder("<"), copy=False).tobytes()
+            shape = b"".join(_field(2, 2, (lambda d: _put_varint(len(d)) + d)(_field(1, 0, _put_varint(int(s))))) for s in a.shape)
+            entry = _field(1, 0, _put_varint(_DTYPE_IDS[a.dtype])) + _field(2, 2, _put_varint(len(shape)) + shape)
+            entry += _field(4, 0, _put_varint(data.tell())) + _field(5, 0, _put_varint(len(raw)))
+            entry += _field(6, 5, struct.pack("<I", _mask_crc(crc32c(raw))))
+            items.append((name.encode(), entry))
+            data.write(raw)
+    with open(prefix + ".index", "wb") as f:
+        index_items, cur, cur_bytes = [], [], 0
+        for kv in items:
+            cur.append(kv); cur_bytes += len(kv[0]) + len(kv[1]) + 3
+            if cur_bytes >= block_size:
+                off, size = _emit_block(f, _build_block(cur))
+                index_items.append((cur[-1][0], _put_varint(off) + _put_varint(size)))
+                cur, cur_bytes = [], 0
+        if cur:
+            off, size = _emit_block(f, _build_block(cur))
+            index_items.append((cur[-1][0], _put_varint(off) + _put_varint(size)))
+        moff, msize = _emit_block(f, _build_block([]))
+        ioff, isize = _emit_block(f, _build_block(index_items, restart_interval=1))
+        footer = _put_varint(moff) + _put_varint(msize) + _put_varint(ioff) + _put_varint(isize)
+        f.write(footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", _MAGIC))
+
+
+# ------------------------------------------------------------------------------------------------ StabNet variable names
+STABNET_SCOPE = "stable_net/resnet/"       # s_net_bundle_nobm.py:251 (`with tf.variable_scope('resnet')` under 'stable_net')
+
+
+def load_stabnet_variables(prefix: str):
+    """(params, extras): params = the regressor's variables keyed the way NetPlan.pack expects (scope stripped); extras = Adam
+    slots (`.../Adam`, `.../Adam_1`), `beta1_power`, `beta2_power`, `global_step` and anything else found."""
+    allv = read_bundle(prefix)
+    params, extras = {}, {}
+    for k, v in allv.items():
+        name = k[len(STABNET_SCOPE):] if k.startswith(STABNET_SCOPE) else k
+        if k.startswith(STABNET_SCOPE) and not (name.endswith("/Adam") or name.endswith("/Adam_1")):
+            params[name] = np.asarray(v, np.float32)
+        else:
+            extras[k] = v
+    return params, extras
+
+
+def load_imagenet_resnet(prefix: str):
+    """train_bundle_nobm.py:184-191,101-102: the ImageNet `resnet_v2_50.ckpt` initialises every variable under
+    `stable_net/resnet/` except `resnet_v2_50/conv1` (13 input channels instead of 3) and the `fc` head; a variable
+    `stable_net/resnet/<name>` is read from the checkpoint's `<name>` (name_in_checkpoint strips the 18-character scope).
+    -> {name without scope: array} of the variables to copy over a fresh initialisation."""
+    out = {}
+    for k, v in read_bundle(prefix).items():
+        if not k.startswith("resnet_v2_50/") or k.startswith("resnet_v2_50/conv1/") or "logits" in k:
+            continue
+        if "Adam" in k or k.endswith("/Momentum"):
+            continue
+        out[k] = np.asarray(v, np.float32)
+    return out

@@ -4,7 +4,8 @@
 Same flags as the reference CLI (deploy_bundle.py:12-31).  What runs on the GPU is the part the reference times
 (deploy_bundle.py:285-287): 13-channel stack -> regressor -> multi-grid warp, plus the history ring and the feedback,
 which the reference does in NumPy on the host.  Differences forced by the offline image, stated rather than hidden:
-  * TensorFlow checkpoints / .meta graphs cannot be read here: --model-dir/--model-name take a `.npz` written by
+  * --model-dir/--model-name take either a TF checkpoint prefix (`model-80000.index` + `.data-*`, read by
+    stabnet_amd/tf_checkpoint.py without TensorFlow; the `.meta` graph is not needed) or a `.npz` written by
     train_bundle_nobm.py (TF variable names); without one, seeded synthetic weights are used and said so.
   * OpenCV is absent: clips are `.npy` arrays ([T,H,W] grey in [0,255] or [T,H,W,3] BGR) under
     <prefix>/unstable/<name>; results are written as `.npy` (stabilised grey frames, x/y maps, black masks).  With
@@ -75,7 +76,13 @@ def load_weights(args, cfg):
                 z = np.load(cand)
                 print('restored weights from', cand)
                 return {k: z[k] for k in z.files if not k.startswith('__')}
-        print('WARNING: %s(.npz) not found; TF1 .meta/.ckpt files cannot be read offline' % path)
+        if os.path.exists(path + '.index'):
+            # the reference's own checkpoint format (new_saver.restore, deploy_bundle.py:45-47): read without TensorFlow
+            from stabnet_amd import tf_checkpoint
+            params, _ = tf_checkpoint.load_stabnet_variables(path)
+            print('restored weights from TF checkpoint', path)
+            return params
+        print('WARNING: neither %s.npz nor %s.index found' % (path, path))
     print('using seeded synthetic weights (no trained model is available offline)')
     return synthetic.make_params(cfg, seed=0, theta_scale=0.2)
 

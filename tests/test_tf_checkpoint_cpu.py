@@ -1,0 +1,71 @@
+"""TF checkpoint (tensor bundle) reader/writer: round trip, table-format structure checks, CRC known answers, scope mapping.
+Parity against a checkpoint written by real TensorFlow is unpinned (none exists offline) -- see the module header."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from stabnet_amd import tf_checkpoint as C
+
+
+def test_crc32c_known_answers():
+    # RFC 3720 B.4 test vectors
+    assert C.crc32c(b"\x00" * 32) == 0x8A9136AA
+    assert C.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert C.crc32c(bytes(range(32))) == 0x46DD794E
+    assert C.crc32c(b"123456789") == 0xE3069283
+    assert C.crc32c(b"6789", C.crc32c(b"12345")) == 0xE3069283          # incremental
+
+
+def test_bundle_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    names = ["stable_net/resnet/resnet_v2_50/block%d/unit_%d/bottleneck_v2/conv%d/weights" % (b, u, c)
+             for b in range(1, 5) for u in range(1, 4) for c in range(1, 4)]
+    var = {n: rng.standard_normal((1, 1, 8, 4)).astype(np.float32) for n in names}      # enough keys for several table blocks
+    var["stable_net/resnet/fc/fc_weights"] = rng.standard_normal((512, 50)).astype(np.float32)
+    var["stable_net/resnet/fc/fc_weights/Adam"] = np.zeros((512, 50), np.float32)
+    var["global_step"] = np.array(80000, np.int64)
+    var["beta1_power"] = np.array(0.9 ** 5, np.float32)
+    prefix = str(tmp_path / "model-80000")
+    C.write_bundle(prefix, var, block_size=512)
+    raw = open(prefix + ".index", "rb").read()
+    assert struct.unpack("<Q", raw[-8:])[0] == 0xDB4775248B80FB57
+    got = C.read_bundle(prefix, verify_crc_below=1 << 30)
+    assert set(got) == set(var)
+    for k in var:
+        assert got[k].dtype == var[k].dtype and got[k].shape == var[k].shape and np.array_equal(got[k], var[k]), k
+    params, extras = C.load_stabnet_variables(prefix)
+    assert "fc/fc_weights" in params and "resnet_v2_50/block1/unit_1/bottleneck_v2/conv1/weights" in params
+    assert "stable_net/resnet/fc/fc_weights/Adam" in extras and int(extras["global_step"]) == 80000
+    assert not any(k.endswith("/Adam") for k in params)
+
+
+def test_corruption_is_detected(tmp_path):
+    prefix = str(tmp_path / "m")
+    C.write_bundle(prefix, {"a": np.arange(6, dtype=np.float32).reshape(2, 3)})
+    data = prefix + ".data-00000-of-00001"
+    b = bytearray(open(data, "rb").read()); b[5] ^= 0x40
+    open(data, "wb").write(bytes(b))
+    with pytest.raises(ValueError, match="crc mismatch"):
+        C.read_bundle(prefix)
+    idx = prefix + ".index"
+    b = bytearray(open(idx, "rb").read()); b[-1] ^= 1
+    open(idx, "wb").write(bytes(b))
+    with pytest.raises(ValueError, match="bad magic"):
+        C.read_bundle(prefix)
+
+
+def test_checkpoint_feeds_the_plan_layout(tmp_path):
+    """A full synthetic StabNet parameter set written as a TF checkpoint under the reference's scope comes back as the dict
+    NetPlan.pack() consumes (names, HWIO / [in,out] layouts untouched)."""
+    from stabnet_amd import synthetic
+    from stabnet_amd.config import Config
+    cfg = Config(height=64, width=64)
+    P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
+    small = {k: v for k, v in P.items() if v.size <= 4096}                               # keep the CPU test quick
+    prefix = str(tmp_path / "model-1")
+    C.write_bundle(prefix, {C.STABNET_SCOPE + k: v for k, v in small.items()})
+    params, extras = C.load_stabnet_variables(prefix)
+    assert not extras and set(params) == set(small)
+    assert all(np.array_equal(params[k], small[k]) for k in small)

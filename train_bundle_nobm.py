@@ -5,7 +5,8 @@ Flags of the reference (train_bundle_nobm.py:34-37) are kept; the loop mirrors t
 loss-schedule gates from the step index, display every disp_freq, checkpoint every save_freq, 10 held-out batches
 every test_freq, Adam with the staircase learning rate.  Differences forced by the offline image:
   * no TFRecord dataset / ImageNet resnet_v2_50.ckpt exists here: batches come from the seeded synthetic generator
-     and weights start from the seeded initialiser; checkpoints are `.npz` of TF-named variables.
+    (SURVEY.md 8d); the ImageNet checkpoint is read (stabnet_amd/tf_checkpoint.py, no TensorFlow needed) when present,
+    otherwise weights start from the seeded initialiser; checkpoints are `.npz` of TF-named variables.
   * data parallel (new): launch with torchrun, one process per GPU; each rank generates its own shard of the global
     batch, BN statistics stay local, gradients are summed over RCCL.
 """
@@ -31,6 +32,9 @@ def build_parser():
     p.add_argument('--width', type=int, default=None)
     p.add_argument('--model-dir', default=None)
     p.add_argument('--disp-freq', type=int, default=None)
+    p.add_argument('--imagenet-ckpt', default='data_video/resnet_v2_50.ckpt',
+                   help='TF checkpoint that initialises the backbone except conv1 and the fc head (reference: '
+                        'train_bundle_nobm.py:184-191); skipped with a note when the file is absent')
     p.add_argument('--augment', action='store_true',
                    help='assemble every batch on the device from un-augmented pair material with the reference\'s random '
                         'crop / flip / contrast / brightness / homography masks (get_data_mini_after.py)')
@@ -62,8 +66,19 @@ def main():
     torch.cuda.set_device(dev)
     pg = parallel.init_process_group(device=dev)
     N, H, W = cfg.batch_size, cfg.height, cfg.width
-    tr = Trainer(synthetic.make_params(cfg, seed=0, theta_scale=0.2), N, H, W, cfg, device=dev, process_group=pg,
-                 world_size=world)
+    init = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
+    ck_prefix = args.imagenet_ckpt
+    if os.path.exists(ck_prefix + '.index') or os.path.exists(ck_prefix):
+        from stabnet_amd import tf_checkpoint
+        pre = tf_checkpoint.load_imagenet_resnet(ck_prefix)
+        hit = [k for k in pre if k in init and pre[k].shape == init[k].shape]
+        for k in hit:
+            init[k] = pre[k]
+        if rank == 0:
+            print('initialised %d backbone variables from %s' % (len(hit), ck_prefix))
+    elif rank == 0:
+        print('note: %s not found; the backbone starts from the seeded initialiser' % ck_prefix)
+    tr = Trainer(init, N, H, W, cfg, device=dev, process_group=pg, world_size=world)
     if args.restore:
         ck = latest_checkpoint(model_dir)
         if ck:
