@@ -23,6 +23,7 @@ struct ConvArgs {
     int splitk, steps_per_split;
     int cin_real;            // un-padded Cin (algorithmic flop accounting only); 0 = Cin
     unsigned div_hw_mul, div_hw_shift, div_w_mul, div_w_shift;   // exact m / (Ho*Wo) and r / Wo by multiply-high (conv_plan)
+    int in_scale_expected;   // plan-time hint: 1 if the launch will carry an input BN prologue (in_scale is bound later)
     int xcd_swizzle;         // 1: remap workgroup ids so each XCD (own 4 MiB L2) works on a contiguous run of M tiles
 };
 

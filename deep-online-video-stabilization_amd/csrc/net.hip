@@ -162,6 +162,7 @@ static Step conv_step(Net& net, const TensorRef& in, const TensorRef& out, int K
     a.res_H = res ? res->H : out.H; a.res_W = res ? res->W : out.W; a.res_stride = res ? res_stride : 1;
     a.relu_out = 0;
     a.cin_real = real_cin ? real_cin : in.C;
+    a.in_scale_expected = bn_off >= 0 ? 1 : 0;
     s.splitk_bytes = conv_plan(a);
     net.splitk_bytes = std::max(net.splitk_bytes, s.splitk_bytes);
     s.in_off = in.off; s.out_off = out.off; s.res_off = res ? res->off : NONE;
@@ -260,6 +261,12 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             net->steps[i_conv1].obn_off = bn1;
             net->steps[i_conv2].obn_off = bn2;
             net->steps[i_conv2].inf_preactivated = 1;
+            if (!keep_all) {            // inference plan: conv2 runs prologue-free (ring kernel) -> its own split-K choice
+                Step& c2 = net->steps[i_conv2];
+                c2.conv.in_scale_expected = 0;
+                c2.splitk_bytes = conv_plan(c2.conv);
+                net->splitk_bytes = std::max(net->splitk_bytes, c2.splitk_bytes);
+            }
             net->bns.push_back({bn2, b.dbn, r2.off, (long)N * r2.H * r2.W, r2.H, r2.W});
             TensorRef nxt = new_tensor(ar, N, Ho, Wo, b.depth);
             {
@@ -268,6 +275,12 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
                 // identity shortcut of a strided unit = subsample(x, stride): read the residual at (oy*s, ox*s)
                 net->steps.push_back(conv_step(*net, r2, nxt, 1, 1, 0, w, bb, bn2, &sc, own_sc ? 1 : stride));
                 net->steps.back().inf_preactivated = 1;
+                if (!keep_all) {
+                    Step& c3 = net->steps.back();
+                    c3.conv.in_scale_expected = 0;
+                    c3.splitk_bytes = conv_plan(c3.conv);
+                    net->splitk_bytes = std::max(net->splitk_bytes, c3.splitk_bytes);
+                }
                 ui.w3 = w; ui.b3 = bb;
             }
             ui.sc = sc; ui.r1 = r1; ui.r2 = r2; ui.out = nxt; ui.proj = own_sc; ui.bn1 = bn1; ui.bn2 = bn2;

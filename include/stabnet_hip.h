@@ -69,6 +69,9 @@ int stabnet_interp_fwd(const float* im, const float* x, const float* y, int N, i
 size_t stabnet_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 /* Tuning hook (tools/autotune.py): force tile (0 128x128, 1 128x64, 2 64x64; < 0 = built-in choice) and split-K. */
 void stabnet_conv_tuning_override(int tile, int splitk);
+/* Tuning hook (tools/tune_splitk.py): measured split-K of one convolution shape; ring = 1 for prologue-free launches.
+ * splitk <= 0 removes the entry, M < 0 clears the table.  Applies to plans made afterwards. */
+void stabnet_conv_tuning_table_set(int M, int Cout, int K, int KH, int ring, int splitk);
 int stabnet_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, const float* in_scale,
                        const float* in_shift, const float* residual, int res_H, int res_W, int res_stride, float* y,
                        int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu_out,
