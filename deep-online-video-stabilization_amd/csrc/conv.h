@@ -23,6 +23,10 @@ struct ConvArgs {
     int splitk, steps_per_split;
     int cin_real;            // un-padded Cin (algorithmic flop accounting only); 0 = Cin
     unsigned div_hw_mul, div_hw_shift, div_w_mul, div_w_shift;   // exact m / (Ho*Wo) and r / Wo by multiply-high (conv_plan)
+    int rowrun;              // 1: "row-run" A operand (ring kernel MODE 2, the 13-channel stem): for every filter row kh the KW*Cin
+                             //    input floats of a tap row are contiguous; they are taken as ONE run, zero-padded to a multiple of 32,
+                             //    so K = KH * roundup(KW*Cin, 32) and the weights are [Cout][KH][roundup(KW*Cin, 32)].  Cin is the
+                             //    real (unpadded) pixel stride; no prologue.
     int in_scale_expected;   // plan-time hint: 1 if the launch will carry an input BN prologue (in_scale is bound later)
     int xcd_swizzle;         // 1: remap workgroup ids so each XCD (own 4 MiB L2) works on a contiguous run of M tiles
 };

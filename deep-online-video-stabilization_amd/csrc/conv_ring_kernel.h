@@ -32,7 +32,7 @@ typedef const __attribute__((address_space(1))) void* sn_gbl_ptr_t;
 
 __device__ __attribute__((aligned(16))) float g_conv_zero_page[8];      // zero-initialised device storage
 
-template <int MODE /* 0: no padding, 1: zero padding */>
+template <int MODE /* 0: no padding, 1: zero padding, 2: row-run A operand on a zero-BORDERED image (ConvArgs::rowrun) */>
 __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     constexpr int BM = 64, BN = 64, BK = 32;
     constexpr int STAGE = (BM + BN) * BK;                  // floats
@@ -44,8 +44,9 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     const int tiles_mn = tiles_m * tiles_n;
     const int ntiles = tiles_mn * p.splitk;                // K slice slowest, then M tile, N tile fastest
     const int G = gridDim.x;
-    const int cin_steps = p.Cin / BK;
-    const int total_steps = p.KH * p.KW * cin_steps;
+    const int cin_steps = (MODE == 2) ? 1 : p.Cin / BK;
+    const int run_steps = (MODE == 2) ? p.K / (p.KH * BK) : 0;     // K-steps per filter row (MODE 2)
+    const int total_steps = (MODE == 2) ? p.K / BK : p.KH * p.KW * cin_steps;
     const int last_slice_steps = total_steps - (p.splitk - 1) * p.steps_per_split;
     const unsigned lds_base = (unsigned)(size_t)(sn_lds_ptr_t)ring;
 
@@ -63,8 +64,8 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     int pt = blockIdx.x;                                   // tile id; >= ntiles: exhausted
     int p_left = 0;                                        // stages of tile `pt` still to issue
     unsigned a_voff[2], w_voff[2];
-    unsigned long long a_mask[2];
-    int l_tap = 0, l_c0 = 0, l_kw = 0;
+    unsigned long long a_mask[2];                          // MODE 1: tap bits per row
+    int l_tap = 0, l_c0 = 0, l_kw = 0;                     // MODE 2: l_tap = filter row kh, l_kw = 32-float step inside its run
     const float *xb = p.x, *wb = p.w;
     auto producer_setup = [&]() {
         const int z = pt / tiles_mn;
@@ -73,37 +74,66 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         const int m0 = mt * BM, n0 = nt * BN;
         const int ks_begin = z * p.steps_per_split;
         p_left = (z == p.splitk - 1) ? last_slice_steps : p.steps_per_split;
+        if constexpr (MODE == 2) {
+            // The image carries its zero border in memory ([N][H+2pad][W+2pad][Cin], written by the stack assembly): every
+            // tap of every output pixel is in the buffer, and for one filter row the KW*Cin floats of the taps are ONE
+            // contiguous run starting at padded pixel (oy*stride + kh, ox*stride).  Rows start at arbitrary 4-byte offsets
+            // (Cin = 13): global_load_lds_dwordx4 takes them (tools/glds_unaligned_probe.hip: correct, 87 % of the aligned
+            // rate).  The run is read 32 floats at a time up to roundup(KW*Cin, 32): the excess multiplies zero weights.
+            const int Wp = p.W + 2 * p.pad, Hp = p.H + 2 * p.pad;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = 8 * (wave + 4 * t) + rr;
-            const int cl = cp ^ ((row >> 1) & 7);          // logical chunk this lane fetches (swizzle on the source side)
-            const int m = m0 + row;
-            const int mc = min(m, p.M - 1);
-            const int img = sn_fastdiv(mc, p.div_hw_mul, p.div_hw_shift);
-            const int r = mc - img * (p.Ho * p.Wo);
-            const int oy = sn_fastdiv(r, p.div_w_mul, p.div_w_shift), ox = r - oy * p.Wo;
-            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-            a_voff[t] = (unsigned)(((img * p.H + iy0 + p.pad) * p.W + ix0 + p.pad) * p.Cin + cl * 4);
-            unsigned long long mk = 0;
-            if (MODE == 1 && m < p.M) {
-                // taps (kh, kw) in frame: kh in [kh_lo, kh_hi), kw in [kw_lo, kw_hi): a run of KW-bit row patterns
-                const int kh_lo = max(0, -iy0), kh_hi = min(p.KH, p.H - iy0);
-                const int kw_lo = max(0, -ix0), kw_hi = min(p.KW, p.W - ix0);
-                if (kh_hi > kh_lo && kw_hi > kw_lo) {
-                    const unsigned long long rowbits = ((1ull << (kw_hi - kw_lo)) - 1ull) << kw_lo;
-                    for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * p.KW);
-                }
+            for (int t = 0; t < 2; ++t) {
+                const int row = 8 * (wave + 4 * t) + rr;
+                const int cl = cp ^ ((row >> 1) & 7);
+                const int mc = min(m0 + row, p.M - 1);
+                const int img = sn_fastdiv(mc, p.div_hw_mul, p.div_hw_shift);
+                const int r = mc - img * (p.Ho * p.Wo);
+                const int oy = sn_fastdiv(r, p.div_w_mul, p.div_w_shift), ox = r - oy * p.Wo;
+                a_voff[t] = (unsigned)(((img * Hp + oy * p.stride) * Wp + ox * p.stride) * p.Cin + cl * 4);
+                a_mask[t] = 0;
+                const int n = min(n0 + row, p.Cout - 1);
+                w_voff[t] = (unsigned)(n * p.K + cl * 4);
             }
-            a_mask[t] = mk;
-            const int n = min(n0 + row, p.Cout - 1);       // rows >= Cout are never stored
-            w_voff[t] = (unsigned)(n * p.K + cl * 4);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int row = 8 * (wave + 4 * t) + rr;
+                const int cl = cp ^ ((row >> 1) & 7);          // logical chunk this lane fetches (swizzle on the source side)
+                const int m = m0 + row;
+                const int mc = min(m, p.M - 1);
+                const int img = sn_fastdiv(mc, p.div_hw_mul, p.div_hw_shift);
+                const int r = mc - img * (p.Ho * p.Wo);
+                const int oy = sn_fastdiv(r, p.div_w_mul, p.div_w_shift), ox = r - oy * p.Wo;
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                a_voff[t] = (unsigned)(((img * p.H + iy0 + p.pad) * p.W + ix0 + p.pad) * p.Cin + cl * 4);
+                unsigned long long mk = 0;
+                if (MODE == 1 && m < p.M) {
+                    // taps (kh, kw) in frame: kh in [kh_lo, kh_hi), kw in [kw_lo, kw_hi): a run of KW-bit row patterns
+                    const int kh_lo = max(0, -iy0), kh_hi = min(p.KH, p.H - iy0);
+                    const int kw_lo = max(0, -ix0), kw_hi = min(p.KW, p.W - ix0);
+                    if (kh_hi > kh_lo && kw_hi > kw_lo) {
+                        const unsigned long long rowbits = ((1ull << (kw_hi - kw_lo)) - 1ull) << kw_lo;
+                        for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * p.KW);
+                    }
+                }
+                a_mask[t] = mk;
+                const int n = min(n0 + row, p.Cout - 1);       // rows >= Cout are never stored
+                w_voff[t] = (unsigned)(n * p.K + cl * 4);
+            }
         }
-        l_tap = ks_begin / cin_steps;
-        l_c0 = (ks_begin - l_tap * cin_steps) * BK;
-        const int l_kh = l_tap / p.KW;
-        l_kw = l_tap - l_kh * p.KW;
-        xb = p.x + ((l_kh * p.W + l_kw) * p.Cin + l_c0 - pad_off);
-        wb = p.w + (l_tap * p.Cin + l_c0);
+        if constexpr (MODE == 2) {
+            l_tap = ks_begin / run_steps;                  // filter row kh
+            l_kw = ks_begin - l_tap * run_steps;           // run step s within the row
+            xb = p.x + ((long)l_tap * (p.W + 2 * p.pad) * p.Cin + 32 * l_kw);
+            wb = p.w + (size_t)ks_begin * BK;
+        } else {
+            l_tap = ks_begin / cin_steps;
+            l_c0 = (ks_begin - l_tap * cin_steps) * BK;
+            const int l_kh = l_tap / p.KW;
+            l_kw = l_tap - l_kh * p.KW;
+            xb = p.x + ((l_kh * p.W + l_kw) * p.Cin + l_c0 - pad_off);
+            wb = p.w + (l_tap * p.Cin + l_c0);
+        }
     };
     // Issue one stage into ring slot `slot` (no-op when every tile of this workgroup has been issued), in four parts so
     // that the K loop can place each DMA (and its address arithmetic) in the shadow of an MFMA.
@@ -129,6 +159,10 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         }
         xb += BK;
         wb += BK;
+        if constexpr (MODE == 2) {
+            if (++l_kw == run_steps) { l_kw = 0; ++l_tap; xb += (p.W + 2 * p.pad) * p.Cin - BK * run_steps; }
+            return;
+        }
         l_c0 += BK;
         if (l_c0 == p.Cin) {
             l_c0 = 0;
@@ -136,9 +170,15 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
             if (++l_kw == p.KW) { l_kw = 0; xb += row_jump; }
         }
     };
+    // the stage's DMAs in four parts (each is placed behind one MFMA of the K loop)
+    auto issue_part = [&](int slot, int part) {
+        if (part == 0) issue_a(slot, 0);
+        else if (part == 1) { issue_a(slot, 1); issue_b(slot, 0); }
+        else if (part == 2) issue_b(slot, 1);
+        else issue_advance();
+    };
     auto issue = [&](int slot) {
-        issue_a(slot, 0); issue_a(slot, 1); issue_b(slot, 0); issue_b(slot, 1);
-        issue_advance();
+        issue_part(slot, 0); issue_part(slot, 1); issue_part(slot, 2); issue_part(slot, 3);
     };
 
     // ---- consumer state: the tile being accumulated
@@ -258,13 +298,13 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
             SN_BARRIER();
             SN_READ0(0, OFF_NEXT);
         }
-        if (feed) { issue_a(SLOT, 0); __builtin_amdgcn_sched_barrier(0); }     // stage k+3 into the slot just retired
+        if (feed) { issue_part(SLOT, 0); __builtin_amdgcn_sched_barrier(0); }   // stage k+3 into the slot just retired
         SN_MFMA1(a1, b1, y);
-        if (feed) { issue_a(SLOT, 1); issue_b(SLOT, 0); __builtin_amdgcn_sched_barrier(0); }
+        if (feed) { issue_part(SLOT, 1); __builtin_amdgcn_sched_barrier(0); }
         SN_MFMA1(a1, b1, z);
-        if (feed) { issue_b(SLOT, 1); __builtin_amdgcn_sched_barrier(0); }
+        if (feed) { issue_part(SLOT, 2); __builtin_amdgcn_sched_barrier(0); }
         SN_MFMA1(a1, b1, w);
-        if (feed) { issue_advance(); __builtin_amdgcn_sched_barrier(0); }
+        if (feed) { issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0); }
         if (tile_done) {
             if (more) SN_WAIT0();                          // the next tile's first fragments: landed before the epilogue code
             else SN_BARRIER();                             // (otherwise the barrier above already retired slot SLOT)

@@ -138,6 +138,27 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, co
     }
 }
 
+// OHWI [Cout][KH][KW][CinPad] -> row-run layout [Cout][KH][Rp], Rp = roundup(KW*Cin, 32): element kw*Cin + c, zeros behind.
+__global__ __launch_bounds__(256) void stem_repack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int KH,
+                                                          int KW, int CinPad, int Cin, int Rp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cout * KH * Rp) return;
+    const int e = i % Rp, kh = (i / Rp) % KH, n = i / (Rp * KH);
+    float v = 0.f;
+    if (e < KW * Cin) {
+        const int kw = e / Cin, c = e - kw * Cin;
+        v = w[(((size_t)n * KH + kh) * KW + kw) * CinPad + c];
+    }
+    out[i] = v;
+}
+
+int launch_stem_repack(const float* w, float* out, int Cout, int KH, int KW, int CinPad, int Cin, hipStream_t st) {
+    const int Rp = (KW * Cin + 31) / 32 * 32;
+    stem_repack_kernel<<<cdiv((long)Cout * KH * Rp, 256), 256, 0, st>>>(w, out, Cout, KH, KW, CinPad, Cin, Rp);
+    SN_LAUNCH_CHECK("stem_repack_kernel");
+    return STABNET_OK;
+}
+
 int launch_pad_channels(const float* x, float* y, long npix, int C, int Cp, hipStream_t st) {
     SN_REQUIRE(Cp % 4 == 0 && Cp >= C, "pad_channels: bad channel counts %d -> %d", C, Cp);
     pad_channels_kernel<<<cdiv(npix * (Cp / 4), 256), 256, 0, st>>>(x, y, npix, C, Cp);

@@ -94,6 +94,8 @@ struct BnInfo { long chan_off; int C; long tensor_off; long M; int H, W; };
 
 struct Net {
     int N, H, W, in_ch, in_ch_pad, n_theta, keep_all;
+    int stem_rowrun = 0, in_ch_act = 0;            // inference plans read the 13-channel stack directly (ring kernel MODE 2)
+    size_t stem_w_floats = 0;                     // re-laid-out stem weights [64][7][roundup(7*in_ch, 32)] behind the folded BN
     std::vector<UnitInfo> units;
     std::vector<BnInfo> bns;
     TensorRef t_xin{}, t_c1{}, t_pool{}, t_last{}, t_gap{}, t_fc[3]{};
@@ -153,7 +155,7 @@ static void same_pads(int n, int k, int s, int& before, int& out) {
 }
 
 static Step conv_step(Net& net, const TensorRef& in, const TensorRef& out, int KH, int stride, int pad, long w_off,
-                      long b_off, long bn_off, const TensorRef* res, int res_stride, int real_cin = 0) {
+                      long b_off, long bn_off, const TensorRef* res, int res_stride, int real_cin = 0, int rowrun = 0) {
     Step s{};
     s.kind = S_CONV;
     ConvArgs& a = s.conv;
@@ -163,6 +165,7 @@ static Step conv_step(Net& net, const TensorRef& in, const TensorRef& out, int K
     a.relu_out = 0;
     a.cin_real = real_cin ? real_cin : in.C;
     a.in_scale_expected = bn_off >= 0 ? 1 : 0;
+    a.rowrun = rowrun;
     s.splitk_bytes = conv_plan(a);
     net.splitk_bytes = std::max(net.splitk_bytes, s.splitk_bytes);
     s.in_off = in.off; s.out_off = out.off; s.res_off = res ? res->off : NONE;
@@ -176,12 +179,20 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
     Net* net = new Net();
     net->N = N; net->H = H; net->W = W; net->in_ch = in_ch; net->n_theta = n_theta; net->keep_all = keep_all;
     net->in_ch_pad = (in_ch + 15) / 16 * 16;
+    static const int want_rowrun = []() { const char* v = getenv("STABNET_STEM_ROWRUN"); return v ? atoi(v) : 1; }();
+    net->stem_rowrun = (!keep_all && want_rowrun && 7 * in_ch <= 128) ? 1 : 0;
+    net->in_ch_act = net->stem_rowrun ? in_ch : net->in_ch_pad;
+    net->stem_w_floats = net->stem_rowrun ? (size_t)64 * 7 * 32 * ((7 * in_ch + 31) / 32) : 0;
     Arena ar;
     auto done = [&](const TensorRef& t) { if (!keep_all) ar.release((size_t)t.off, t.size); };
     const std::string R = "resnet_v2_50/";
 
     // stem: conv2d_same(64, 7, stride 2) with bias, no BN/ReLU; then max_pool2d 3x3/2 SAME
-    TensorRef xin = new_tensor(ar, N, H, W, net->in_ch_pad);
+    // inference (row-run stem): the stack lives as a tight in_ch-channel image with a 3-pixel zero border (+ one slack row:
+    // the last run of the last row reads up to 31 floats past its taps); training: channels padded to 16, no border
+    const int border = net->stem_rowrun ? 3 : 0;
+    TensorRef xin = net->stem_rowrun ? new_tensor(ar, N, H + 2 * border + 1, W + 2 * border, in_ch)
+                                     : new_tensor(ar, N, H, W, net->in_ch_act);
     {
         Step s{};
         s.kind = S_PAD; s.in_off = EXT_IN; s.out_off = xin.off; s.N = N; s.H = H; s.W = W; s.C = in_ch;
@@ -192,7 +203,9 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
     {
         const long w = (long)net->add_param(R + "conv1/weights", PK_CONV_W, 64, 7, 7, net->in_ch_pad, in_ch);
         const long b = (long)net->add_param(R + "conv1/biases", PK_BIAS, 64, 0, 0, 0, 0);
-        net->steps.push_back(conv_step(*net, xin, c1, 7, 2, 3, w, b, NONE, nullptr, 1, in_ch));
+        TensorRef xlog = xin;                   // logical (unbordered) geometry of the same buffer
+        xlog.H = H; xlog.W = W;
+        net->steps.push_back(conv_step(*net, xlog, c1, 7, 2, 3, w, b, NONE, nullptr, 1, in_ch, net->stem_rowrun));
         net->w_stem = w; net->b_stem = b;
     }
     net->t_xin = xin; net->t_c1 = c1;
@@ -364,13 +377,14 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
         const bool rec = (s.kind != S_CONV) && prof != nullptr && prof->begin(st);
         switch (s.kind) {
             case S_PAD:
-                rc = launch_pad_channels(x, ws + s.out_off, (long)s.N * s.H * s.W, s.C, net->in_ch_pad, st);
+                if (net->stem_rowrun) rc = launch_embed_border(x, s.N, s.H, s.W, s.C, 3, ws + s.out_off, st);
+                else rc = launch_pad_channels(x, ws + s.out_off, (long)s.N * s.H * s.W, s.C, net->in_ch_act, st);
                 break;
             case S_CONV: {
                 ConvArgs a = s.conv;
                 a.x = ws + s.in_off;
                 a.y = ws + s.out_off;
-                a.w = params + s.w_off;
+                a.w = a.rowrun ? fold + 2 * net->G : params + s.w_off;
                 a.bias = s.b_off >= 0 ? params + s.b_off : nullptr;
                 a.residual = s.res_off >= 0 ? ws + s.res_off : nullptr;
                 const bool prologue = s.bn_off >= 0 && !s.inf_preactivated;
@@ -475,7 +489,7 @@ const char* stabnet_prof_kind_name(int kind) {
         case PK_KERNEL_FC: return "fc_kernel";
         case PK_KERNEL_MESH: return "mesh_homography_kernel";
         case PK_KERNEL_WARP: return "warp_sample_kernel";
-        case PK_KERNEL_ASSEMBLE: return "stack_assemble_kernel";
+        case PK_KERNEL_ASSEMBLE: return "stack_assemble_bordered_kernel";
         case PK_KERNEL_PUSH: return "ring_push_kernel";
         case PK_KERNEL_SPLITK_REDUCE: return "conv_splitk_reduce_kernel";
         case PK_KERNEL_WGRAD: return "conv_wgrad_f32_kernel";
@@ -483,6 +497,7 @@ const char* stabnet_prof_kind_name(int kind) {
     }
     if (kind == PK_KERNEL_CONV_RING) return "conv_ring_f32_kernel<0>";
     if (kind == PK_KERNEL_CONV_RING + 1) return "conv_ring_f32_kernel<1>";
+    if (kind == PK_KERNEL_CONV_RING + 2) return "conv_ring_f32_kernel<2>";
     if (kind >= PK_KERNEL_CONV_BASE && kind < PK_KERNEL_CONV_BASE + 18) {
         // names as rocprofv3 prints the template instantiation: <BM, BN, BK, WM, WN, MODE, NBUF>
         static thread_local char buf[96];
@@ -559,8 +574,18 @@ int stabnet_net_activation_info(const void* netp, const char* name, long* offset
 int stabnet_net_fold_bn(const void* netp, const float* params, float* fold, float eps, void* stream) {
     const Net* net = static_cast<const Net*>(netp);
     SN_REQUIRE(net && params && fold, "fold_bn: null pointer");
-    return launch_bn_fold(params + net->off_gamma, params + net->off_beta, params + net->off_mean,
-                          params + net->off_var, eps, (int)net->G, fold, fold + net->G, (hipStream_t)stream);
+    int rc = launch_bn_fold(params + net->off_gamma, params + net->off_beta, params + net->off_mean,
+                            params + net->off_var, eps, (int)net->G, fold, fold + net->G, (hipStream_t)stream);
+    if (rc || !net->stem_rowrun) return rc;
+    // stem weights OHWI [64][7][7][in_ch_pad] -> row-run layout [64][7][roundup(7*in_ch, 32)] (zeros in the run padding)
+    return launch_stem_repack(params + net->w_stem, fold + 2 * net->G, 64, 7, 7, net->in_ch_pad, net->in_ch,
+                              (hipStream_t)stream);
+}
+
+/* Floats of the `fold` buffer: [G scales][G shifts][re-laid-out stem weights of an inference plan]. */
+size_t stabnet_net_fold_floats(const void* netp) {
+    const Net* net = static_cast<const Net*>(netp);
+    return net ? 2 * net->G + net->stem_w_floats : 0;
 }
 
 /* get_resnet(x_tensor, is_training=False): x_tensor NHWC [N,H,W,in_ch] -> theta [N,n_theta]. */
@@ -622,8 +647,11 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
     float* x16 = ws + net->steps[0].out_off;
     for (int j = 0; j < refine; ++j) {
         bool rec = prof && prof->begin(st);
-        rc = launch_stack_assemble(frames_ring, masks_ring, cur, net->N, depth, head, rl, hw, net->in_ch_pad, x16, st);
-        if (rec) prof->end(st, PK_KERNEL_ASSEMBLE, 0, 4.0 * net->N * hw * (net->in_ch + net->in_ch_pad));
+        if (net->stem_rowrun)
+            rc = launch_stack_assemble_bordered(frames_ring, masks_ring, cur, net->N, depth, head, rl, net->H, net->W, 3, x16, st);
+        else
+            rc = launch_stack_assemble(frames_ring, masks_ring, cur, net->N, depth, head, rl, hw, net->in_ch_act, x16, st);
+        if (rec) prof->end(st, PK_KERNEL_ASSEMBLE, 0, 4.0 * net->N * hw * (net->in_ch + net->in_ch_act));
         if (rc) return rc;
         rc = run_forward(net, params, fold, nullptr, theta, ws, st, prof, true);
         if (rc) return rc;

@@ -53,6 +53,67 @@ __global__ __launch_bounds__(256) void stack_assemble_kernel(const float* __rest
     }
 }
 
+// The inference stem (ring kernel MODE 2) reads the stack as a tight 13-channel image WITH its zero border in memory:
+// out[s][Hp][Wp][Cp], Hp = H + 2*border, Wp = W + 2*border, Cp = 2n+1.  One thread per bordered pixel; the block's 256 pixels
+// x Cp floats are one contiguous run of the output, written coalesced through LDS.  The border is rewritten every frame
+// (the arena may have reused the region in between).
+__global__ __launch_bounds__(256) void stack_assemble_bordered_kernel(const float* __restrict__ frames,
+                                                                      const float* __restrict__ masks,
+                                                                      const float* __restrict__ cur, int depth,
+                                                                      const int* __restrict__ head_ptr, const RingLags lags,
+                                                                      int H, int W, int border, int Cp, float* __restrict__ out) {
+    __shared__ float tile[256 * 16];
+    const int Wp = W + 2 * border, Hp = H + 2 * border;
+    const long hwp = (long)Hp * Wp, hw = (long)H * W;
+    const long i0 = (long)blockIdx.x * 256;
+    const long ip = i0 + threadIdx.x;
+    const int s = blockIdx.y;
+    const int head = *head_ptr;
+    const int n = lags.n;
+    if (ip < hwp) {
+        const int yp = (int)(ip / Wp), xp = (int)(ip - (long)yp * Wp);
+        const int y = yp - border, x = xp - border;
+        float* t = tile + threadIdx.x * Cp;
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+            const long i = (long)y * W + x;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                if (l < n) {
+                    int slot = (head - lags.lag[l]) % depth;
+                    if (slot < 0) slot += depth;
+                    const long off = ((long)s * depth + slot) * hw + i;
+                    t[l] = masks[off];
+                    t[n + l] = frames[off];
+                }
+            }
+            t[2 * n] = cur[(long)s * hw + i];
+        } else {
+            for (int c = 0; c < Cp; ++c) t[c] = 0.f;
+        }
+    }
+    __syncthreads();
+    const long npix = min((long)256, hwp - i0);
+    float* o = out + ((long)s * hwp + i0) * Cp;
+    for (long k = threadIdx.x; k < npix * Cp; k += 256) o[k] = tile[k];
+}
+
+// x [N][H][W][C] -> out [N][H+2b][W+2b][C] with a zero border (the non-deploy entry of the same stem).
+__global__ __launch_bounds__(256) void embed_border_kernel(const float* __restrict__ x, int H, int W, int C, int border,
+                                                           float* __restrict__ out) {
+    const int Wp = W + 2 * border, Hp = H + 2 * border;
+    const long total = (long)Hp * Wp * C;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    const int n = blockIdx.y;
+    const long pix = q / C;
+    const int c = (int)(q - pix * C);
+    const int yp = (int)(pix / Wp), xp = (int)(pix - (long)yp * Wp);
+    const int y = yp - border, xx = xp - border;
+    float v = 0.f;
+    if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = x[(((long)n * H + y) * W + xx) * C + c];
+    out[(long)n * total + q] = v;
+}
+
 // frame = img + black * (-1) (:293); push frame and black into slot `head` (:322-323).
 __global__ __launch_bounds__(256) void ring_push_kernel(float* __restrict__ frames, float* __restrict__ masks, int depth,
                                                         const int* __restrict__ head_ptr, const float* __restrict__ img,
@@ -81,6 +142,23 @@ int launch_stack_assemble(const float* frames, const float* masks, const float* 
                lags.n, Cp);
     stack_assemble_kernel<<<dim3(cdiv(hw, 256), S), 256, 0, st>>>(frames, masks, cur, depth, head, lags, hw, Cp, out);
     SN_LAUNCH_CHECK("stack_assemble_kernel");
+    return STABNET_OK;
+}
+
+int launch_stack_assemble_bordered(const float* frames, const float* masks, const float* cur, int S, int depth, const int* head,
+                                   const RingLags& lags, int H, int W, int border, float* out, hipStream_t st) {
+    SN_REQUIRE(lags.n >= 1 && lags.n <= 7 && border >= 0, "stack_assemble: bad arguments");
+    const long hwp = (long)(H + 2 * border) * (W + 2 * border);
+    stack_assemble_bordered_kernel<<<dim3(cdiv(hwp, 256), S), 256, 0, st>>>(frames, masks, cur, depth, head, lags, H, W, border,
+                                                                          2 * lags.n + 1, out);
+    SN_LAUNCH_CHECK("stack_assemble_bordered_kernel");
+    return STABNET_OK;
+}
+
+int launch_embed_border(const float* x, int N, int H, int W, int C, int border, float* out, hipStream_t st) {
+    const long total = (long)(H + 2 * border) * (W + 2 * border) * C;
+    embed_border_kernel<<<dim3(cdiv(total, 256), N), 256, 0, st>>>(x, H, W, C, border, out);
+    SN_LAUNCH_CHECK("embed_border_kernel");
     return STABNET_OK;
 }
 

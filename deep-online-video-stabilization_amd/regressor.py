@@ -95,7 +95,7 @@ class Regressor:
         self.plan = NetPlan(N, H, W, cfg, keep_activations)
         flat = params if isinstance(params, np.ndarray) and params.ndim == 1 else self.plan.pack(params)
         self.params = torch.from_numpy(np.ascontiguousarray(flat)).to(self.device)
-        self.fold = torch.empty(2 * self.plan.bn_channels, dtype=torch.float32, device=self.device)
+        self.fold = torch.empty(int(_lib.lib().stabnet_net_fold_floats(self.plan.handle)), dtype=torch.float32, device=self.device)
         self.workspace = torch.empty(self.plan.workspace_bytes, dtype=torch.uint8, device=self.device)
         self.refold()
 

@@ -112,6 +112,9 @@ int stabnet_net_activation_info(const void* net, const char* name, long* offset,
 /* slim batch_norm(is_training=False) folded to per-channel (scale, shift): fold = [G scales][G shifts],
  * G = stabnet_net_bn_channels().  scale = rsqrt(var + eps) * gamma, shift = beta - mean * scale. */
 int stabnet_net_fold_bn(const void* net, const float* params, float* fold, float eps, void* stream);
+/* Floats the caller must allocate for `fold`: 2*bn_channels, plus the re-laid-out stem weights of an inference plan
+ * (keep_activations = 0), which reads the 13-channel stack directly (no channel padding). */
+size_t stabnet_net_fold_floats(const void* net);
 
 /* x_tensor NHWC [N,H,W,in_ch] -> theta [N,n_theta]; BN in moving-average mode (s_net_bundle_nobm.py:302). */
 int stabnet_backbone_fwd_infer(const void* net, const float* params, const float* fold, const float* x_tensor,

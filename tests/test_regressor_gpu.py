@@ -43,7 +43,8 @@ def test_regressor_taps_and_theta(cuda, N, H, W):
     # same result with activation-buffer reuse (the deploy configuration)
     reg2 = Regressor(P, N, H, W, cfg, keep_activations=False)
     theta2 = reg2(torch.from_numpy(x).to(cuda))
-    assert torch.equal(theta, theta2)
+    # (the inference plan's stem sums its taps in a different order: 13-channel row runs instead of 16-channel pixels)
+    assert (theta - theta2).abs().max().item() <= 2e-6
 
 
 def test_full_frame_matches_oracle(cuda):

@@ -9,13 +9,16 @@ void stabnet_set_error(const char*, ...) {}
 int main(int argc, char** argv) {
     const int H = argc > 1 ? atoi(argv[1]) : 1, W = argc > 2 ? atoi(argv[2]) : 16384, Cin = argc > 3 ? atoi(argv[3]) : 1152;
     const int N = argc > 4 ? atoi(argv[4]) : 128, KH = argc > 5 ? atoi(argv[5]) : 1;
-    const int M = H * W, K = KH * KH * Cin;
+    const bool stem = argc > 7 && atoi(argv[7]) == 1;       // row-run stem geometry: stride 2, pad KH/2, K = KH*roundup(KH*Cin,32)
+    const int st_ = stem ? 2 : 1;
+    const int Ho = (H + 2 * (KH / 2) - KH) / st_ + 1, Wo = (W + 2 * (KH / 2) - KH) / st_ + 1;
+    const int M = Ho * Wo, K = stem ? KH * ((KH * Cin + 31) / 32 * 32) : KH * KH * Cin;
     ConvArgs a{};
     float *x, *w, *y;
-    (void)hipMalloc(&x, (size_t)M * Cin * 4); (void)hipMalloc(&w, (size_t)N * K * 4); (void)hipMalloc(&y, (size_t)M * N * 4);
-    (void)hipMemset(x, 0, (size_t)M * Cin * 4); (void)hipMemset(w, 0, (size_t)N * K * 4);
-    a.x = x; a.w = w; a.y = y; a.N = 1; a.H = H; a.W = W; a.Cin = Cin; a.Cout = N; a.KH = KH; a.KW = KH; a.stride = 1; a.pad = KH / 2;
-    a.up = 1; a.Ho = H; a.Wo = W; a.res_H = H; a.res_W = W; a.res_stride = 1; a.M = M; a.K = K; a.splitk = 1;
+    (void)hipMalloc(&x, (size_t)(H + 8) * (W + 8) * Cin * 4 + 1024); (void)hipMalloc(&w, (size_t)N * K * 4); (void)hipMalloc(&y, (size_t)M * N * 4);
+    (void)hipMemset(x, 0, (size_t)(H + 8) * (W + 8) * Cin * 4 + 1024); (void)hipMemset(w, 0, (size_t)N * K * 4);
+    a.x = x; a.w = w; a.y = y; a.N = 1; a.H = H; a.W = W; a.Cin = Cin; a.Cout = N; a.KH = KH; a.KW = KH; a.stride = st_; a.pad = KH / 2; a.rowrun = stem ? 1 : 0;
+    a.up = 1; a.Ho = Ho; a.Wo = Wo; a.res_H = Ho; a.res_W = Wo; a.res_stride = 1; a.M = M; a.K = K; a.splitk = 1;
     sn_fastdiv_make((unsigned)(a.Ho * a.Wo), a.div_hw_mul, a.div_hw_shift); sn_fastdiv_make((unsigned)a.Wo, a.div_w_mul, a.div_w_shift);
     a.steps_per_split = K / 32;
     dim3 grid((M + 63) / 64, (N + 63) / 64, 1);
@@ -23,7 +26,8 @@ int main(int argc, char** argv) {
     const int wgs = argc > 6 ? atoi(argv[6]) : 768;
     const int g1 = (int)std::min<size_t>(nblk, (size_t)wgs);
     auto launch = [&]() {
-        if (KH == 1) conv_ring_f32_kernel<0><<<g1, 256>>>(a);
+        if (stem) conv_ring_f32_kernel<2><<<g1, 256>>>(a);
+        else if (KH == 1) conv_ring_f32_kernel<0><<<g1, 256>>>(a);
         else conv_ring_f32_kernel<1><<<g1, 256>>>(a);
     };
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
