@@ -176,6 +176,34 @@ int wgrad_launch(const float* x, const float* dy, float* dw, const float* in_sca
     return STABNET_OK;
 }
 
+// All dgrad weight tensors of a net in ONE launch (the per-layer version cost 104 launches of ~6 us per training step).
+// The layer table travels as a kernel argument; a thread finds its layer by binary search over the element prefix sums.
+__global__ __launch_bounds__(256) void pack_dgrad_weights_all_kernel(const float* __restrict__ params, float* __restrict__ wt,
+                                                                     const PackTable t) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= t.prefix[t.n]) return;
+    int lo = 0, hi = t.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.prefix[mid] <= q) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc d = t.d[lo];
+    const long e = q - t.prefix[lo];
+    const int co = (int)(e % d.Cout);
+    long r = e / d.Cout;
+    const int kw = (int)(r % d.K); r /= d.K;
+    const int kh = (int)(r % d.K);
+    const int ci = (int)(r / d.K);
+    wt[q] = params[d.w_off + (((size_t)co * d.K + (d.K - 1 - kh)) * d.K + (d.K - 1 - kw)) * d.Cin + ci];
+}
+
+int pack_dgrad_weights_all(const float* params, float* wt, const PackTable& t, hipStream_t st) {
+    if (t.n == 0) return STABNET_OK;
+    pack_dgrad_weights_all_kernel<<<cdiv(t.prefix[t.n], 256), 256, 0, st>>>(params, wt, t);
+    SN_LAUNCH_CHECK("pack_dgrad_weights_all_kernel");
+    return STABNET_OK;
+}
+
 int pack_dgrad_weights(const float* w, float* wt, int Cout, int KH, int KW, int Cin, hipStream_t st) {
     const long total = (long)Cout * KH * KW * Cin;
     pack_dgrad_weights_kernel<<<cdiv(total, 256), 256, 0, st>>>(w, wt, Cout, KH, KW, Cin);

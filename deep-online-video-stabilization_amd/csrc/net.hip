@@ -95,7 +95,9 @@ struct BnInfo { long chan_off; int C; long tensor_off; long M; int H, W; };
 struct Net {
     int N, H, W, in_ch, in_ch_pad, n_theta, keep_all;
     int stem_rowrun = 0, in_ch_act = 0;            // inference plans read the 13-channel stack directly (ring kernel MODE 2)
-    size_t stem_w_floats = 0;                     // re-laid-out stem weights [64][7][roundup(7*in_ch, 32)] behind the folded BN
+    size_t stem_w_floats = 0;
+    PackTable packs{};                            // dgrad weight re-pack of every unit conv (training)
+    long pack_w3[16] = {0}, pack_w2[16] = {0}, pack_w1[16] = {0}, pack_sc[16] = {0};   // wt offsets per unit                     // re-laid-out stem weights [64][7][roundup(7*in_ch, 32)] behind the folded BN
     std::vector<UnitInfo> units;
     std::vector<BnInfo> bns;
     TensorRef t_xin{}, t_c1{}, t_pool{}, t_last{}, t_gap{}, t_fc[3]{};
@@ -360,6 +362,24 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             e.off += base[s];
             net->params.push_back(e);
         }
+    {   // dgrad weight re-pack table, in the order run_backward consumes it
+        PackTable& t = net->packs;
+        t.n = 0; t.prefix[0] = 0;
+        auto add = [&](long w_off, int Cout, int K, int Cin) -> long {
+            const long off = t.prefix[t.n];
+            t.d[t.n] = {w_off, Cout, K, Cin, 0};
+            t.prefix[t.n + 1] = off + (long)Cout * K * K * Cin;
+            ++t.n;
+            return off;
+        };
+        for (size_t ui = 0; ui < net->units.size() && ui < 16; ++ui) {
+            const UnitInfo& u = net->units[ui];
+            net->pack_w3[ui] = add(u.w3, u.depth, 1, u.dbn);
+            net->pack_w2[ui] = add(u.w2, u.dbn, 3, u.dbn);
+            net->pack_w1[ui] = add(u.w1, u.dbn, 1, u.cin);
+            net->pack_sc[ui] = u.proj ? add(u.w_sc, u.depth, 1, u.cin) : -1;
+        }
+    }
     net->act_floats = ar.peak;
     net->splitk_bytes = std::max(net->splitk_bytes, sizeof(float) * (size_t)N * gap_chunks(net->t_last.H * net->t_last.W) * net->t_last.C);
     net->max_net = std::max({net->max_net, net->t_c1.size, net->t_pool.size});
@@ -715,7 +735,7 @@ static TrainLayout train_layout(const Net* net) {
     red = std::max(red, col_reduce_workspace_floats((long)net->t_c1.N * net->t_c1.H * net->t_c1.W, 64));
     L.partial = take(red);
     L.coef = take(3 * std::max<size_t>(net->max_c, 2048));
-    L.wt = take(net->max_w);
+    L.wt = take((size_t)net->packs.prefix[net->packs.n]);
     L.argmax = take((net->t_pool.size + 3) / 4);              // one byte per pooled element
     size_t sk = net->splitk_bytes;
     for (const UnitInfo& u : net->units) {
@@ -809,6 +829,7 @@ static int run_backward(const Net* net, const float* params, const float* d_thet
                                   (long)xt.N * xt.H * xt.W, xt.C, addend, add_stride, xt.H, xt.W, grads + net->off_gamma + bn,
                                   grads + net->off_beta + bn, dx, partial, coef, st);
     };
+    if ((rc = pack_dgrad_weights_all(params, wt, net->packs, st)) != 0) return rc;
     // ---- FC head (resnet.py:44-56, s_net_bundle_nobm.py:256-259)
     float* fg[2] = {ws + L.fcg0, ws + L.fcg1};
     const TensorRef* fin[4] = {&net->t_gap, &net->t_fc[0], &net->t_fc[1], &net->t_fc[2]};
@@ -839,26 +860,22 @@ static int run_backward(const Net* net, const float* params, const float* d_thet
         if ((rc = launch_bias_grad(G, Mo, u.depth, grads + u.b3, partial, st)) != 0) return rc;
         if ((rc = wgrad_launch(ws + u.r2.off, G, grads + u.w3, scale + u.bn2, shift + u.bn2, N, u.r2.H, u.r2.W, u.dbn, u.depth,
                                1, 1, 1, 0, st, prof)) != 0) return rc;
-        if ((rc = pack_dgrad_weights(params + u.w3, wt, u.depth, 1, 1, u.dbn, st)) != 0) return rc;
-        if ((rc = dgrad_launch(G, wt, T1, nullptr, N, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
+        if ((rc = dgrad_launch(G, wt + net->pack_w3[ui], T1, nullptr, N, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
         if ((rc = bn_bwd(u.bn2, u.r2, T1, nullptr, 1, T1)) != 0) return rc;                      // T1 = d r2
         // conv2 (3x3, stride) : input relu(bn1(r1))
         if ((rc = wgrad_launch(ws + u.r1.off, T1, grads + u.w2, scale + u.bn1, shift + u.bn1, N, u.r1.H, u.r1.W, u.dbn, u.dbn,
                                3, 3, u.stride, 1, st, prof)) != 0) return rc;
-        if ((rc = pack_dgrad_weights(params + u.w2, wt, u.dbn, 3, 3, u.dbn, st)) != 0) return rc;
-        if ((rc = dgrad_launch(T1, wt, T2, nullptr, N, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, 3, u.stride, 1, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
+        if ((rc = dgrad_launch(T1, wt + net->pack_w2[ui], T2, nullptr, N, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, 3, u.stride, 1, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
         if ((rc = bn_bwd(u.bn1, u.r1, T2, nullptr, 1, T2)) != 0) return rc;                      // T2 = d r1
         // conv1 (1x1) : input relu(bn_pre(x))
         if ((rc = wgrad_launch(ws + u.x.off, T2, grads + u.w1, scale + u.bn_pre, shift + u.bn_pre, N, u.x.H, u.x.W, u.cin, u.dbn,
                                1, 1, 1, 0, st, prof)) != 0) return rc;
-        if ((rc = pack_dgrad_weights(params + u.w1, wt, u.dbn, 1, 1, u.cin, st)) != 0) return rc;
-        if ((rc = dgrad_launch(T2, wt, T3, nullptr, N, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
+        if ((rc = dgrad_launch(T2, wt + net->pack_w1[ui], T3, nullptr, N, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
         if (u.proj) {   // projection shortcut conv1x1(preact) + bias: d preact += dgrad(G)
             if ((rc = launch_bias_grad(G, Mo, u.depth, grads + u.b_sc, partial, st)) != 0) return rc;
             if ((rc = wgrad_launch(ws + u.x.off, G, grads + u.w_sc, scale + u.bn_pre, shift + u.bn_pre, N, u.x.H, u.x.W, u.cin,
                                    u.depth, 1, 1, 1, 0, st, prof)) != 0) return rc;
-            if ((rc = pack_dgrad_weights(params + u.w_sc, wt, u.depth, 1, 1, u.cin, st)) != 0) return rc;
-            if ((rc = dgrad_launch(G, wt, T3, T3, N, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
+            if ((rc = dgrad_launch(G, wt + net->pack_sc[ui], T3, T3, N, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
             if ((rc = bn_bwd(u.bn_pre, u.x, T3, nullptr, 1, GB)) != 0) return rc;
         } else {        // identity shortcut (subsample by the unit's stride): d x += upsample(G)
             if ((rc = bn_bwd(u.bn_pre, u.x, T3, G, u.stride, GB)) != 0) return rc;

@@ -27,6 +27,11 @@ int launch_adam(float* w, const float* g, const float* g2, float* m, float* v, l
 int wgrad_launch(const float* x, const float* dy, float* dw, const float* in_scale, const float* in_shift, int N, int H,
                  int W, int Cin, int Cout, int KH, int KW, int stride, int pad, hipStream_t st, Prof* prof);
 int pack_dgrad_weights(const float* w, float* wt, int Cout, int KH, int KW, int Cin, hipStream_t st);
+// every dgrad weight tensor of a net, re-packed by one launch: layer i = params[w_off ...] OHWI [Cout][K][K][Cin] ->
+// wt[prefix[i] ...] as [Cin][K][K][Cout] with both filter axes flipped
+struct PackDesc { long w_off; int Cout, K, Cin, pad_; };
+struct PackTable { PackDesc d[56]; long prefix[57]; int n; };
+int pack_dgrad_weights_all(const float* params, float* wt, const PackTable& t, hipStream_t st);
 int dgrad_launch(const float* dy, const float* wt, float* dx, const float* residual, int N, int H, int W, int Cin,
                  int Cout, int KH, int KW, int stride, int pad, float* splitk_ws, size_t splitk_bytes, hipStream_t st,
                  Prof* prof);
