@@ -30,6 +30,9 @@ CASES = [
     (1, 36, 64, 64, 64, 3, 1, 2, False, False, 0, False),    # pad 2 (full correlation, the stride-1 dgrad geometry)
     (1, 9, 16, 512, 512, 3, 1, 1, False, False, 0, True),    # split-K through the ring kernel
     (1, 18, 32, 128, 512, 1, 2, 0, False, True, 2, False),   # strided 1x1 (shortcut) + strided residual read
+    (1, 180, 320, 64, 64, 3, 1, 1, False, True, 1, True),    # 900 tiles > 768 resident workgroups: several tiles per
+                                                             # workgroup, the ring running across tile boundaries (MODE 1)
+    (1, 180, 320, 32, 256, 1, 1, 0, False, False, 1, False), # 3600 one-step tiles: every step is a tile boundary (MODE 0)
 ]
 
 
