@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     // ---- producer state: the tile whose stages are being issued
     int pt = blockIdx.x;                                   // tile id; >= ntiles: exhausted
     int p_left = 0;                                        // stages of tile `pt` still to issue
-    unsigned a_voff[2], w_voff[2];
+    unsigned a_voff[2], w_voff[2];                         // BYTE offsets from the running pointers xb / wb
     unsigned long long a_mask[2];                          // MODE 1: tap bits per row
     int l_tap = 0, l_c0 = 0, l_kw = 0;                     // MODE 2: l_tap = filter row kh, l_kw = 32-float step inside its run
     const float *xb = p.x, *wb = p.w;
@@ -89,10 +89,10 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
                 const int img = sn_fastdiv(mc, p.div_hw_mul, p.div_hw_shift);
                 const int r = mc - img * (p.Ho * p.Wo);
                 const int oy = sn_fastdiv(r, p.div_w_mul, p.div_w_shift), ox = r - oy * p.Wo;
-                a_voff[t] = (unsigned)(((img * Hp + oy * p.stride) * Wp + ox * p.stride) * p.Cin + cl * 4);
+                a_voff[t] = 4u * (unsigned)(((img * Hp + oy * p.stride) * Wp + ox * p.stride) * p.Cin + cl * 4);
                 a_mask[t] = 0;
                 const int n = min(n0 + row, p.Cout - 1);
-                w_voff[t] = (unsigned)(n * p.K + cl * 4);
+                w_voff[t] = 4u * (unsigned)(n * p.K + cl * 4);
             }
         } else {
 #pragma unroll
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
                 const int r = mc - img * (p.Ho * p.Wo);
                 const int oy = sn_fastdiv(r, p.div_w_mul, p.div_w_shift), ox = r - oy * p.Wo;
                 const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-                a_voff[t] = (unsigned)(((img * p.H + iy0 + p.pad) * p.W + ix0 + p.pad) * p.Cin + cl * 4);
+                a_voff[t] = 4u * (unsigned)(((img * p.H + iy0 + p.pad) * p.W + ix0 + p.pad) * p.Cin + cl * 4);
                 unsigned long long mk = 0;
                 if (MODE == 1 && m < p.M) {
                     // taps (kh, kw) in frame: kh in [kh_lo, kh_hi), kw in [kw_lo, kw_hi): a run of KW-bit row patterns
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
                 }
                 a_mask[t] = mk;
                 const int n = min(n0 + row, p.Cout - 1);       // rows >= Cout are never stored
-                w_voff[t] = (unsigned)(n * p.K + cl * 4);
+                w_voff[t] = 4u * (unsigned)(n * p.K + cl * 4);
             }
         }
         if constexpr (MODE == 2) {
@@ -138,17 +138,32 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     // Issue one stage into ring slot `slot` (no-op when every tile of this workgroup has been issued), in four parts so
     // that the K loop can place each DMA (and its address arithmetic) in the shadow of an MFMA.
     const unsigned dma_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)wave * 1024u));
+    // The DMA itself is inline asm in the SGPR-base + 32-bit lane-offset form (`global_load_lds_dwordx4 voff, s[base]`):
+    // the builtin materialises a 64-bit per-lane address with vector ALU instructions, and every VALU instruction takes
+    // issue slots from the f32 MFMAs.  M0 carries the wave-uniform LDS destination.
+    auto dma16 = [&](const float* base_, unsigned voff_bytes, unsigned lds_byte) {
+        // (the running pointers are wave-uniform; readfirstlane says so to the register allocator and folds away when the
+        //  value already lives in SGPRs)
+        const unsigned long long b64 = (unsigned long long)(size_t)base_;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+        const float* base = reinterpret_cast<const float*>((size_t)(((unsigned long long)hi << 32) | lo));
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(base), "s"(lds_byte) : "memory", "m0");
+    };
     auto issue_a = [&](int slot, int t) {
         if (pt >= ntiles || (RING_ABLATE & 1)) return;
-        const float* src = xb + a_voff[t];
-        if (MODE == 1) src = ((a_mask[t] >> l_tap) & 1ull) ? src : zero_page;
-        __builtin_amdgcn_global_load_lds((sn_gbl_ptr_t)src, (sn_lds_ptr_t)(size_t)(dma_base + (unsigned)(slot * STAGE * 4 + t * 4096)),
-                                         16, 0, 0);
+        const unsigned lds_byte = dma_base + (unsigned)(slot * STAGE * 4 + t * 4096);
+        if constexpr (MODE == 1) {
+            // out-of-frame taps read the zero page: a per-lane choice between two unrelated addresses needs the 64-bit form
+            const float* src = ((a_mask[t] >> l_tap) & 1ull) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(xb) + a_voff[t]) : zero_page;
+            __builtin_amdgcn_global_load_lds((sn_gbl_ptr_t)src, (sn_lds_ptr_t)(size_t)lds_byte, 16, 0, 0);
+        } else {
+            dma16(xb, a_voff[t], lds_byte);
+        }
     };
     auto issue_b = [&](int slot, int t) {
         if (pt >= ntiles || (RING_ABLATE & 1)) return;
-        __builtin_amdgcn_global_load_lds((sn_gbl_ptr_t)(wb + w_voff[t]),
-                                         (sn_lds_ptr_t)(size_t)(dma_base + (unsigned)(slot * STAGE * 4 + BM * BK * 4 + t * 4096)), 16, 0, 0);
+        dma16(wb, w_voff[t], dma_base + (unsigned)(slot * STAGE * 4 + BM * BK * 4 + t * 4096));
     };
     auto issue_advance = [&]() {
         if (pt >= ntiles) return;
