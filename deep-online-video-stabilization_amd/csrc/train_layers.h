@@ -5,6 +5,9 @@
 struct Prof;
 
 size_t col_reduce_workspace_floats(long M, int C);
+int launch_bn_stats_finalize(const float* partial, int chunks, long M, int C, const float* gamma, const float* beta, float eps,
+                             float decay, float* scale, float* shift, float* save_mean, float* save_invstd, float* mov_mean,
+                             float* mov_var, hipStream_t st);
 int launch_bn_stats(const float* x, long M, int C, const float* gamma, const float* beta, float eps, float decay,
                     float* scale, float* shift, float* save_mean, float* save_invstd, float* mov_mean, float* mov_var,
                     float* partial, hipStream_t st);

@@ -63,14 +63,16 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
     }
 }
 
-// Sum of the chunk partials for 64 channels per block: 4 lanes per channel walk the chunks (float64), fixed-order
-// combine through LDS (deterministic).  Returns the two sums in lane 0 of each channel.
+// Sum of the chunk partials for 64 channels per block: 16 lanes per channel walk the chunks (float64), fixed-order combine
+// through LDS (deterministic).  Returns the two sums in lane 0 of each channel.  Blocks are 64 x 16 = 1024 threads: the
+// conv-epilogue statistics come as one partial row per 32 pixels (thousands of chunks for the block1 tensors).
+constexpr int FIN_LANES = 16;
 __device__ __forceinline__ void combine_partials(const float* __restrict__ partial, int chunks, int C, int c, int lane,
                                                  double& s0, double& s1) {
-    __shared__ double sh0[4][64], sh1[4][64];
+    __shared__ double sh0[FIN_LANES][64], sh1[FIN_LANES][64];
     double a0 = 0.0, a1 = 0.0;
     if (c < C)
-        for (int k = lane; k < chunks; k += 4) {
+        for (int k = lane; k < chunks; k += FIN_LANES) {
             a0 += (double)partial[(size_t)k * 2 * C + c];
             a1 += (double)partial[(size_t)k * 2 * C + C + c];
         }
@@ -78,13 +80,13 @@ __device__ __forceinline__ void combine_partials(const float* __restrict__ parti
     sh1[lane][threadIdx.x & 63] = a1;
     __syncthreads();
     const int t = threadIdx.x & 63;
-    s0 = ((sh0[0][t] + sh0[1][t]) + sh0[2][t]) + sh0[3][t];
-    s1 = ((sh1[0][t] + sh1[1][t]) + sh1[2][t]) + sh1[3][t];
+    s0 = sh0[0][t]; s1 = sh1[0][t];
+    for (int i = 1; i < FIN_LANES; ++i) { s0 += sh0[i][t]; s1 += sh1[i][t]; }
 }
 
 // BN statistics finalize: batch mean / biased variance (float64 combine) -> folded (scale, shift), saved (mean, invstd),
 // moving averages.  grid = C/64 blocks of 256 threads.
-__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int chunks, long M, int C,
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __restrict__ partial, int chunks, long M, int C,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float eps, float decay, float* __restrict__ scale,
                                                                 float* __restrict__ shift, float* __restrict__ save_mean,
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
 
 // BN backward finalize: d_gamma += sum dz*xhat, d_beta += sum dz; coefficients for the apply pass:
 // coef[0][c] = gamma*invstd, coef[1][c] = mean(dz), coef[2][c] = mean(dz*xhat).
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, long M, int C,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, long M, int C,
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                               float* __restrict__ d_gamma, float* __restrict__ d_beta,
                                                               float* __restrict__ coef) {
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     coef[2 * C + c] = (float)(sx / (double)M);
 }
 
-__global__ __launch_bounds__(256) void bias_grad_finalize_kernel(const float* __restrict__ partial, int chunks, int C,
+__global__ __launch_bounds__(1024) void bias_grad_finalize_kernel(const float* __restrict__ partial, int chunks, int C,
                                                                  float* __restrict__ d_bias) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
     double s, unused;
@@ -359,6 +361,16 @@ size_t col_reduce_workspace_floats(long M, int C) {
     return (size_t)chunks * 2 * C;
 }
 
+// statistics from partial rows [chunks][2][C] (written by col_reduce_kernel<0> or by the convolution epilogue)
+int launch_bn_stats_finalize(const float* partial, int chunks, long M, int C, const float* gamma, const float* beta, float eps,
+                             float decay, float* scale, float* shift, float* save_mean, float* save_invstd, float* mov_mean,
+                             float* mov_var, hipStream_t st) {
+    bn_stats_finalize_kernel<<<cdiv(C, 64), 64 * FIN_LANES, 0, st>>>(partial, chunks, M, C, gamma, beta, eps, decay, scale, shift,
+                                                                     save_mean, save_invstd, mov_mean, mov_var);
+    SN_LAUNCH_CHECK("bn_stats_finalize_kernel");
+    return STABNET_OK;
+}
+
 int launch_bn_stats(const float* x, long M, int C, const float* gamma, const float* beta, float eps, float decay,
                     float* scale, float* shift, float* save_mean, float* save_invstd, float* mov_mean, float* mov_var,
                     float* partial, hipStream_t st) {
@@ -367,10 +379,8 @@ int launch_bn_stats(const float* x, long M, int C, const float* gamma, const flo
     const int chunks = reduce_chunks(M, rpc);
     col_reduce_kernel<0><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, rpc, partial);
     SN_LAUNCH_CHECK("col_reduce_kernel<0>");
-    bn_stats_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(partial, chunks, M, C, gamma, beta, eps, decay, scale, shift,
-                                                           save_mean, save_invstd, mov_mean, mov_var);
-    SN_LAUNCH_CHECK("bn_stats_finalize_kernel");
-    return STABNET_OK;
+    return launch_bn_stats_finalize(partial, chunks, M, C, gamma, beta, eps, decay, scale, shift, save_mean, save_invstd, mov_mean,
+                                    mov_var, st);
 }
 
 int launch_bn_relu_bwd(const float* x, const float* g, const float* scale, const float* shift, const float* mean,
@@ -381,7 +391,7 @@ int launch_bn_relu_bwd(const float* x, const float* g, const float* scale, const
     const int chunks = reduce_chunks(M, rpc);
     col_reduce_kernel<1><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(x, g, scale, shift, mean, invstd, M, C, rpc, partial);
     SN_LAUNCH_CHECK("col_reduce_kernel<1>");
-    bn_bwd_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(partial, chunks, M, C, gamma, invstd, d_gamma, d_beta, coef);
+    bn_bwd_finalize_kernel<<<cdiv(C, 64), 64 * FIN_LANES, 0, st>>>(partial, chunks, M, C, gamma, invstd, d_gamma, d_beta, coef);
     SN_LAUNCH_CHECK("bn_bwd_finalize_kernel");
     bn_bwd_apply_kernel<<<cdiv(M * (C / 4), 256), 256, 0, st>>>(x, g, scale, shift, mean, invstd, coef, addend, add_stride, H,
                                                                 W, M, C, d_x);
@@ -395,7 +405,7 @@ int launch_bias_grad(const float* g, long M, int C, float* d_bias, float* partia
     const int chunks = reduce_chunks(M, rpc);
     col_reduce_kernel<2><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(nullptr, g, nullptr, nullptr, nullptr, nullptr, M, C, rpc, partial);
     SN_LAUNCH_CHECK("col_reduce_kernel<2>");
-    bias_grad_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(partial, chunks, C, d_bias);
+    bias_grad_finalize_kernel<<<cdiv(C, 64), 64 * FIN_LANES, 0, st>>>(partial, chunks, C, d_bias);
     SN_LAUNCH_CHECK("bias_grad_finalize_kernel");
     return STABNET_OK;
 }
