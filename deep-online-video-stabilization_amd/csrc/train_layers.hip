@@ -349,15 +349,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-static int reduce_chunks(long M, long& rows_per_chunk) {
-    int chunks = (int)std::min<long>(std::max<long>(M / 512, 1), 256);
+// Row chunks of a column reduction over [M][C]: about 2048 blocks in all ((C/64) x chunks; 256 CUs x 8 resident blocks), at
+// least 64 rows per chunk.
+static int reduce_chunks(long M, int C, long& rows_per_chunk) {
+    const long want = std::max<long>(2048 / cdiv(C, 64), 16);
+    int chunks = (int)std::min<long>(std::max<long>(M / 64, 1), want);
     rows_per_chunk = (M + chunks - 1) / chunks;
     return (int)((M + rows_per_chunk - 1) / rows_per_chunk);
 }
 
 size_t col_reduce_workspace_floats(long M, int C) {
     long rpc;
-    const int chunks = reduce_chunks(M, rpc);
+    const int chunks = reduce_chunks(M, C, rpc);
     return (size_t)chunks * 2 * C;
 }
 
@@ -376,7 +379,7 @@ int launch_bn_stats(const float* x, long M, int C, const float* gamma, const flo
                     float* partial, hipStream_t st) {
     SN_REQUIRE(C % 4 == 0, "bn_stats: C %% 4 != 0");
     long rpc;
-    const int chunks = reduce_chunks(M, rpc);
+    const int chunks = reduce_chunks(M, C, rpc);
     col_reduce_kernel<0><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, rpc, partial);
     SN_LAUNCH_CHECK("col_reduce_kernel<0>");
     return launch_bn_stats_finalize(partial, chunks, M, C, gamma, beta, eps, decay, scale, shift, save_mean, save_invstd, mov_mean,
@@ -388,7 +391,7 @@ int launch_bn_relu_bwd(const float* x, const float* g, const float* scale, const
                        int W, float* d_gamma, float* d_beta, float* d_x, float* partial, float* coef, hipStream_t st) {
     SN_REQUIRE(C % 4 == 0, "bn_bwd: C %% 4 != 0");
     long rpc;
-    const int chunks = reduce_chunks(M, rpc);
+    const int chunks = reduce_chunks(M, C, rpc);
     col_reduce_kernel<1><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(x, g, scale, shift, mean, invstd, M, C, rpc, partial);
     SN_LAUNCH_CHECK("col_reduce_kernel<1>");
     bn_bwd_finalize_kernel<<<cdiv(C, 64), 64 * FIN_LANES, 0, st>>>(partial, chunks, M, C, gamma, invstd, d_gamma, d_beta, coef);
@@ -402,7 +405,7 @@ int launch_bn_relu_bwd(const float* x, const float* g, const float* scale, const
 int launch_bias_grad(const float* g, long M, int C, float* d_bias, float* partial, hipStream_t st) {
     SN_REQUIRE(C % 4 == 0, "bias_grad: C %% 4 != 0");
     long rpc;
-    const int chunks = reduce_chunks(M, rpc);
+    const int chunks = reduce_chunks(M, C, rpc);
     col_reduce_kernel<2><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(nullptr, g, nullptr, nullptr, nullptr, nullptr, M, C, rpc, partial);
     SN_LAUNCH_CHECK("col_reduce_kernel<2>");
     bias_grad_finalize_kernel<<<cdiv(C, 64), 64 * FIN_LANES, 0, st>>>(partial, chunks, C, d_bias);
