@@ -331,6 +331,9 @@ __global__ __launch_bounds__(256) void feature_loss_kernel(const float* __restri
 //   losses[0] id2 = mean|theta| * id_mul      (s_net_bundle_nobm.py:263)      losses[1] black_pos (mean hinge^2 * use_black)
 //   losses[2] distortion (:166-181)           losses[3] consistency (:183-210)
 // d_theta = clip_mask * (d_pts2_warp + w_dist * d dist + w_cons * d cons + w_black * d black) + w_id * sign(theta)/(N*nt)
+// The per-sample vertex arrays are indexed dynamically: in LDS (template LDSV) they cost ~5 us, as private arrays they live
+// in scratch memory (128 us for 8 samples).
+template <bool LDSV>
 __global__ __launch_bounds__(64) void mesh_losses_kernel(const float* __restrict__ theta, const float* __restrict__ d_pts2_warp,
                                                          int N, int gh, int gw, float lim, float id_mul, float w_id,
                                                          float w_dist, float w_cons, float use_black, float w_black,
@@ -339,7 +342,10 @@ __global__ __launch_bounds__(64) void mesh_losses_kernel(const float* __restrict
     const int nv = (gh + 1) * (gw + 1), nt = nv * 2;
     __shared__ float red[4][64];
     float l_id = 0.f, l_black = 0.f, l_dist = 0.f, l_cons = 0.f;
-    float p[2 * 81], dp[2 * 81];                       // (gh+1)(gw+1) <= 81 vertices
+    extern __shared__ float mesh_lds[];
+    float p_priv[LDSV ? 1 : 2 * 81], dp_priv[LDSV ? 1 : 2 * 81];      // (gh+1)(gw+1) <= 81 vertices
+    float* const p = LDSV ? mesh_lds + (size_t)n * 4 * nv : p_priv;
+    float* const dp = LDSV ? p + 2 * nv : dp_priv;
     if (n < N) {
         const double hh = 2.0 / gh, ww = 2.0 / gw;
         for (int i = 0; i <= gh; ++i)
@@ -539,8 +545,13 @@ int stabnet_mesh_losses(const float* theta, const float* d_pts2_warp, int N, int
                         float* losses4, float* d_theta, void* stream) {
     SN_REQUIRE(theta && losses4 && d_theta, "mesh_losses: null pointer");
     SN_REQUIRE(N > 0 && N <= 64 && (grid_h + 1) * (grid_w + 1) <= 81 && do_crop_rate > 0.f, "mesh_losses: bad shape");
-    mesh_losses_kernel<<<1, 64, 0, (hipStream_t)stream>>>(theta, d_pts2_warp, N, grid_h, grid_w, 1.0f / do_crop_rate, id_mul,
-                                                          w_id, w_dist, w_cons, use_black, w_black, losses4, d_theta);
+    const size_t lds = (size_t)N * 4 * (grid_h + 1) * (grid_w + 1) * sizeof(float);
+    if (lds <= 60 * 1024)
+        mesh_losses_kernel<true><<<1, 64, lds, (hipStream_t)stream>>>(theta, d_pts2_warp, N, grid_h, grid_w, 1.0f / do_crop_rate,
+                                                                      id_mul, w_id, w_dist, w_cons, use_black, w_black, losses4, d_theta);
+    else
+        mesh_losses_kernel<false><<<1, 64, 0, (hipStream_t)stream>>>(theta, d_pts2_warp, N, grid_h, grid_w, 1.0f / do_crop_rate,
+                                                                     id_mul, w_id, w_dist, w_cons, use_black, w_black, losses4, d_theta);
     SN_LAUNCH_CHECK("mesh_losses_kernel");
     return STABNET_OK;
 }
