@@ -187,24 +187,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 __global__ __launch_bounds__(256) void max_pool_bwd_kernel(const unsigned char* __restrict__ argmax, const float* __restrict__ dy,
                                                            float* __restrict__ dx, int N, int H, int W, int C, int Ho,
                                                            int Wo, int k, int stride, int pt, int pl) {
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)N * H * W * C;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;          // one thread per (input pixel, 4 channels)
+    const int c4n = C / 4;
+    const long total = (long)N * H * W * c4n;
     if (q >= total) return;
-    const int c = (int)(q % C);
-    long r = q / C;
+    const int c = (int)(q % c4n) * 4;
+    long r = q / c4n;
     const int ix = (int)(r % W); r /= W;
     const int iy = (int)(r % H);
     const int n = (int)(r / H);
-    float acc = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int oy_lo = max(0, (iy + pt - k + stride) / stride), oy_hi = min(Ho - 1, (iy + pt) / stride);
     const int ox_lo = max(0, (ix + pl - k + stride) / stride), ox_hi = min(Wo - 1, (ix + pl) / stride);
     for (int oy = oy_lo; oy <= oy_hi; ++oy)
         for (int ox = ox_lo; ox <= ox_hi; ++ox) {
             const long o = (((long)n * Ho + oy) * Wo + ox) * C + c;
-            const int am = argmax[o];
-            if (oy * stride - pt + am / k == iy && ox * stride - pl + am % k == ix) acc += dy[o];
+            const uchar4 am = *reinterpret_cast<const uchar4*>(argmax + o);
+            const float4 g = *reinterpret_cast<const float4*>(dy + o);
+            const int want = (iy - (oy * stride - pt)) * k + (ix - (ox * stride - pl));     // the tap of this window that is (iy, ix)
+            acc.x += (am.x == want) ? g.x : 0.f; acc.y += (am.y == want) ? g.y : 0.f;
+            acc.z += (am.z == want) ? g.z : 0.f; acc.w += (am.w == want) ? g.w : 0.f;
         }
-    dx[q] = acc;
+    *reinterpret_cast<float4*>(dx + (((long)n * H + iy) * W + ix) * C + c) = acc;
 }
 
 // max_pool2d forward that also records the argmax (training).
@@ -415,7 +419,8 @@ int launch_bias_grad(const float* g, long M, int C, float* d_bias, float* partia
 
 int launch_max_pool_bwd(const unsigned char* argmax, const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo,
                         int k, int stride, int pt, int pl, hipStream_t st) {
-    max_pool_bwd_kernel<<<cdiv((long)N * H * W * C, 256), 256, 0, st>>>(argmax, dy, dx, N, H, W, C, Ho, Wo, k, stride, pt, pl);
+    SN_REQUIRE(C % 4 == 0, "max_pool_bwd: C %% 4 != 0");
+    max_pool_bwd_kernel<<<cdiv((long)N * H * W * (C / 4), 256), 256, 0, st>>>(argmax, dy, dx, N, H, W, C, Ho, Wo, k, stride, pt, pl);
     SN_LAUNCH_CHECK("max_pool_bwd_kernel");
     return STABNET_OK;
 }
