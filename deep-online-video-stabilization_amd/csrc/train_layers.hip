@@ -4,6 +4,7 @@
 //   (decay 0.997, variable -= (variable - value) * (1 - decay)); the UPDATE_OPS run with the step (s_net_bundle_nobm.py:355-356).
 #include "train_layers.h"
 #include <algorithm>
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------------
 // Column reductions over an [M][C] tensor, two stages (deterministic order):
@@ -353,10 +354,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Row chunks of a column reduction over [M][C]: about 2048 blocks in all ((C/64) x chunks; 256 CUs x 8 resident blocks), at
-// least 64 rows per chunk.
+// Row chunks of a column reduction over [M][C]: about 512 blocks in all ((C/64) x chunks, two per CU; measured 2048 / 1024 /
+// 768 / 512 / 384 / 256 -> 389.6 / 394.7 / 398.0 / 400.0 / 399.5 / 395.4 pairs/s: more chunks speed the reduction up but
+// slow the single-block-per-64-channels finalize down), at least 64 rows per chunk.
 static int reduce_chunks(long M, int C, long& rows_per_chunk) {
-    const long want = std::max<long>(2048 / cdiv(C, 64), 16);
+    static const int target = []() { const char* v = getenv("STABNET_REDUCE_BLOCKS"); return v ? atoi(v) : 512; }();
+    const long want = std::max<long>(target / cdiv(C, 64), 16);
     int chunks = (int)std::min<long>(std::max<long>(M / 64, 1), want);
     rows_per_chunk = (M + chunks - 1) / chunks;
     return (int)((M + rows_per_chunk - 1) / rows_per_chunk);
