@@ -43,7 +43,19 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.Cout + BN - 1) / BN;
     const int tiles_mn = tiles_m * tiles_n;
     const int ntiles = tiles_mn * p.splitk;                // K slice slowest, then M tile, N tile fastest
-    const int G = gridDim.x;
+    // Tiles of this workgroup: t_first, t_first + t_stride, ... < t_end.  Plain: b, b + G, ...  XCD-aware (xcd_swizzle):
+    // the dispatcher deals workgroup ids round-robin over the 8 XCDs (own 4 MiB L2 each), so the workgroups with equal
+    // b % 8 share an L2; they take one CONTIGUOUS eighth of the tile list (N tile fastest, then M): that XCD then reads
+    // one slice of the input instead of all of it (a 3x3 layer re-reads every input row for 3 tap rows and all N tiles).
+    int t_first = blockIdx.x, t_stride = gridDim.x, t_end = ntiles;
+    if (p.xcd_swizzle && gridDim.x >= 8) {
+        const int x = blockIdx.x & 7, Gt = (int)gridDim.x;
+        t_stride = (Gt - x + 7) >> 3;                      // workgroups of this XCD (ids x, x+8, ...)
+        const int before = x * (Gt >> 3) + min(x, Gt & 7); // workgroups of the XCDs in front of it
+        const int lo = (int)((long)ntiles * before / Gt), hi = (int)((long)ntiles * (before + t_stride) / Gt);
+        t_first = lo + (blockIdx.x >> 3);                  // tile ranges proportional to the workgroup counts: balanced
+        t_end = hi;
+    }
     const int cin_steps = (MODE == 2) ? 1 : p.Cin / BK;
     const int run_steps = (MODE == 2) ? p.K / (p.KH * BK) : 0;     // K-steps per filter row (MODE 2)
     const int total_steps = (MODE == 2) ? p.K / BK : p.KH * p.KW * cin_steps;
@@ -52,7 +64,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
 
     // consumer steps of this workgroup (every slice has steps_per_split steps except the last one)
     int remaining = 0;
-    for (int t = blockIdx.x; t < ntiles; t += G) remaining += (t / tiles_mn == p.splitk - 1) ? last_slice_steps : p.steps_per_split;
+    for (int t = t_first; t < t_end; t += t_stride) remaining += (t / tiles_mn == p.splitk - 1) ? last_slice_steps : p.steps_per_split;
 
     // ---- DMA lane roles: instruction g in {wave, wave + 4} covers tile rows 8g .. 8g+7
     const int rr = lane >> 3, cp = lane & 7;
@@ -61,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     const float* const zero_page = g_conv_zero_page;
 
     // ---- producer state: the tile whose stages are being issued
-    int pt = blockIdx.x;                                   // tile id; >= ntiles: exhausted
+    int pt = t_first;                                      // tile id; >= t_end: exhausted
     int p_left = 0;                                        // stages of tile `pt` still to issue
     unsigned a_voff[2], w_voff[2];                         // BYTE offsets from the running pointers xb / wb
     unsigned long long a_mask[2];                          // MODE 1: tap bits per row
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(base), "s"(lds_byte) : "memory", "m0");
     };
     auto issue_a = [&](int slot, int t) {
-        if (pt >= ntiles || (RING_ABLATE & 1)) return;
+        if (pt >= t_end || (RING_ABLATE & 1)) return;
         const unsigned lds_byte = dma_base + (unsigned)(slot * STAGE * 4 + t * 4096);
         if constexpr (MODE == 1) {
             // out-of-frame taps read the zero page: a per-lane choice between two unrelated addresses needs the 64-bit form
@@ -162,14 +174,14 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         }
     };
     auto issue_b = [&](int slot, int t) {
-        if (pt >= ntiles || (RING_ABLATE & 1)) return;
+        if (pt >= t_end || (RING_ABLATE & 1)) return;
         dma16(wb, w_voff[t], dma_base + (unsigned)(slot * STAGE * 4 + BM * BK * 4 + t * 4096));
     };
     auto issue_advance = [&]() {
-        if (pt >= ntiles) return;
+        if (pt >= t_end) return;
         if (--p_left == 0) {
-            pt += G;
-            if (pt < ntiles) producer_setup();
+            pt += t_stride;
+            if (pt < t_end) producer_setup();
             return;
         }
         xb += BK;
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     };
 
     // ---- consumer state: the tile being accumulated
-    int ct = blockIdx.x, c_left = 0, c_m0 = 0, c_n0 = 0, c_z = 0;
+    int ct = t_first, c_left = 0, c_m0 = 0, c_n0 = 0, c_z = 0;
     auto consumer_setup = [&]() {
         c_z = ct / tiles_mn;
         const int mn = ct - c_z * tiles_mn;
@@ -327,8 +339,8 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
                                 lds_base + (unsigned)(OFF + wave * SN_EPI_WAVE_BYTES));
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-            ct += G;
-            if (ct < ntiles) consumer_setup();
+            ct += t_stride;
+            if (ct < t_end) consumer_setup();
             if (more) {
                 SN_BARRIER();                              // every wave is done with the scratch
                 issue(SLOT);
