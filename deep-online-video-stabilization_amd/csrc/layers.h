@@ -5,7 +5,7 @@
 int launch_stem_repack(const float* w, float* out, int Cout, int KH, int KW, int CinPad, int Cin, hipStream_t st);
 int launch_pad_channels(const float* x, float* y, long npix, int C, int Cp, hipStream_t st);
 int launch_max_pool(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, int k, int stride, int pt,
-                    int pl, hipStream_t st);
+                    int pl, const float* scale, const float* shift, hipStream_t st);
 int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int G,
                    float* scale, float* shift, hipStream_t st);
 int gap_chunks(int HW);   // partial buffer = N * gap_chunks(HW) * C floats

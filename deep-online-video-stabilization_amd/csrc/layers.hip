@@ -24,8 +24,11 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restri
     *reinterpret_cast<float4*>(y + pix * Cp + c) = v;
 }
 
+// (scale, shift) non-null: the consumer's folded BN + ReLU is applied to the pooled value (inference plan: the first unit of
+// block1 has a projection shortcut, so nothing reads the raw pooled tensor).
 __global__ __launch_bounds__(256) void max_pool_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H,
-                                                       int W, int C, int Ho, int Wo, int k, int stride, int pt, int pl) {
+                                                       int W, int C, int Ho, int Wo, int k, int stride, int pt, int pl,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     const int c4n = C / 4;
     const long total = (long)N * Ho * Wo * c4n;
@@ -45,6 +48,11 @@ __global__ __launch_bounds__(256) void max_pool_kernel(const float* __restrict__
             const float4 v = *reinterpret_cast<const float4*>(x + (((long)n * H + iy) * W + ix) * C + c);
             m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
         }
+    }
+    if (scale != nullptr) {
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+        m.x = fmaxf(__builtin_fmaf(m.x, sc.x, sh.x), 0.f); m.y = fmaxf(__builtin_fmaf(m.y, sc.y, sh.y), 0.f);
+        m.z = fmaxf(__builtin_fmaf(m.z, sc.z, sh.z), 0.f); m.w = fmaxf(__builtin_fmaf(m.w, sc.w, sh.w), 0.f);
     }
     *reinterpret_cast<float4*>(y + (((long)n * Ho + oy) * Wo + ox) * C + c) = m;
 }
@@ -167,9 +175,9 @@ int launch_pad_channels(const float* x, float* y, long npix, int C, int Cp, hipS
 }
 
 int launch_max_pool(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, int k, int stride, int pt,
-                    int pl, hipStream_t st) {
+                    int pl, const float* scale, const float* shift, hipStream_t st) {
     SN_REQUIRE(C % 4 == 0, "max_pool: C %% 4 != 0");
-    max_pool_kernel<<<cdiv((long)N * Ho * Wo * (C / 4), 256), 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, k, stride, pt, pl);
+    max_pool_kernel<<<cdiv((long)N * Ho * Wo * (C / 4), 256), 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, k, stride, pt, pl, scale, shift);
     SN_LAUNCH_CHECK("max_pool_kernel");
     return STABNET_OK;
 }

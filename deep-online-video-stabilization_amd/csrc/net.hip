@@ -219,7 +219,7 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
     TensorRef cur = new_tensor(ar, N, H2, W2, 64);
     {
         Step s{};
-        s.kind = S_POOL; s.in_off = c1.off; s.out_off = cur.off;
+        s.kind = S_POOL; s.in_off = c1.off; s.out_off = cur.off; s.obn_off = NONE;
         s.N = N; s.H = H1; s.W = W1; s.C = 64; s.Ho = H2; s.Wo = W2; s.k = 3; s.stride = 2; s.pt = pt; s.pl = pl;
         net->steps.push_back(s);
     }
@@ -243,18 +243,33 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             const int Ho = (cur.H + 2 - 3) / stride + 1, Wo = (cur.W + 2 - 3) / stride + 1;
             TensorRef sc = cur;
             bool own_sc = false;
+            // Inference plan, projection units (the first unit of every block): nothing reads the RAW unit input (the shortcut
+            // is a conv of the pre-activation), so its producer -- the max-pool or the previous block's last conv3 -- applies
+            // this unit's preact BN + ReLU itself and both convs of the unit run prologue-free on the ring kernel.
+            const bool pre_act = !keep_all && cin != b.depth && !net->steps.empty() &&
+                                 (net->steps.back().kind == S_POOL || net->steps.back().kind == S_CONV) &&
+                                 net->steps.back().out_off == cur.off && net->steps.back().obn_off < 0;
+            if (pre_act) net->steps.back().obn_off = bn_pre;
+            auto mark_preactivated = [&](Step& st_) {
+                st_.inf_preactivated = 1;
+                st_.conv.in_scale_expected = 0;
+                st_.splitk_bytes = conv_plan(st_.conv);
+                net->splitk_bytes = std::max(net->splitk_bytes, st_.splitk_bytes);
+            };
             if (cin != b.depth) {       // projection shortcut: conv1x1(preact) + bias, stride 1 here
                 sc = new_tensor(ar, N, cur.H, cur.W, b.depth);
                 own_sc = true;
                 const long w = (long)net->add_param(S + "shortcut/weights", PK_CONV_W, b.depth, 1, 1, cin, cin);
                 const long bb = (long)net->add_param(S + "shortcut/biases", PK_BIAS, b.depth, 0, 0, 0, 0);
                 net->steps.push_back(conv_step(*net, cur, sc, 1, 1, 0, w, bb, bn_pre, nullptr, 1));
+                if (pre_act) mark_preactivated(net->steps.back());
                 ui.w_sc = w; ui.b_sc = bb;
             }
             TensorRef r1 = new_tensor(ar, N, cur.H, cur.W, b.dbn);
             {
                 const long w = (long)net->add_param(S + "conv1/weights", PK_CONV_W, b.dbn, 1, 1, cin, cin);
                 net->steps.push_back(conv_step(*net, cur, r1, 1, 1, 0, w, NONE, bn_pre, nullptr, 1));
+                if (pre_act) mark_preactivated(net->steps.back());
                 ui.w1 = w;
             }
             const size_t i_conv1 = net->steps.size() - 1;
@@ -421,7 +436,7 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
             }
             case S_POOL:
                 rc = launch_max_pool(ws + s.in_off, ws + s.out_off, s.N, s.H, s.W, s.C, s.Ho, s.Wo, s.k, s.stride, s.pt,
-                                     s.pl, st);
+                                     s.pl, s.obn_off >= 0 ? scale + s.obn_off : nullptr, s.obn_off >= 0 ? shift + s.obn_off : nullptr, st);
                 break;
             case S_GAP:
                 rc = launch_gap_bn_relu(ws + s.in_off, scale + s.bn_off, shift + s.bn_off, s.N, s.H * s.W, s.C,
