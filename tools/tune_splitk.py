@@ -27,6 +27,8 @@ def key_of(name, shp):
         return (M, N, K, 1, 1)
     if name.startswith("conv_ring_f32_kernel<1"):
         return (M, N, K, 3, 1)
+    if name.startswith("conv_ring_f32_kernel<2"):
+        return (M, N, K, 7, 1)
     mode = int(name.split(",")[5])
     kh = 1 if mode == 0 else (7 if K == 784 else 3)
     return (M, N, K, kh, 0)
