@@ -13,12 +13,16 @@ struct ConvArgs {
     const float* residual;   // NHWC [N,res_H,res_W,Cout] or null; read at (oy*res_stride, ox*res_stride)
     const float* out_scale;  // [Cout] or null: epilogue  y = y*out_scale + out_shift  (folded BN of the CONSUMER, inference)
     const float* out_shift;
+    const float* out_floor;  // [Cout] or null: with out_scale, y = max(y, out_floor[n]) instead of the relu_out flag (0 = ReLU,
+                             // -inf = none): lets ONE launch produce channels with and without an activation
     float* partial;          // split-K workspace [splitk][M][Cout] (only when splitk > 1)
     // geometry
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
     int up;                  // input dilation ("fractional stride") used by dgrad of strided convs; 1 otherwise
     int res_H, res_W, res_stride;
     int relu_out;
+    int x_ld, res_ld;        // floats between consecutive pixels of x / of the residual (0 = Cin / Cout: dense tensors); the
+                             // inference plan keeps two tensors side by side in one buffer (shortcut | conv1 of a projection unit)
     int M, K;                // M = N*Ho*Wo, K = KH*KW*Cin
     int splitk, steps_per_split;
     int cin_real;            // un-padded Cin (algorithmic flop accounting only); 0 = Cin

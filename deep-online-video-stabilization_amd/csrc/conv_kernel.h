@@ -85,12 +85,12 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvA
             mrow[q] = mw0 + i * 32 + rrow + 8 * q;
             const int m = min(mrow[q], p.M - 1);
             if (!has_res || res_plain) {
-                roff[q] = (unsigned)(m * p.Cout);
+                roff[q] = (unsigned)(m * p.res_ld);
             } else {
                 const int img = sn_fastdiv(m, p.div_hw_mul, p.div_hw_shift);
                 const int rr = m - img * (p.Ho * p.Wo);
                 const int oy = sn_fastdiv(rr, p.div_w_mul, p.div_w_shift), ox = rr - oy * p.Wo;
-                roff[q] = (unsigned)(((img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.Cout);
+                roff[q] = (unsigned)(((img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.res_ld);
             }
         }
 #pragma unroll
@@ -107,6 +107,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvA
             const float4 bv = has_bias ? *reinterpret_cast<const float4*>(p.bias + nc) : zero4;
             const float4 os = has_obn ? *reinterpret_cast<const float4*>(p.out_scale + nc) : zero4;
             const float4 ob = has_obn ? *reinterpret_cast<const float4*>(p.out_shift + nc) : zero4;
+            const bool has_floor = has_obn && p.out_floor != nullptr;
+            const float4 fl = has_floor ? *reinterpret_cast<const float4*>(p.out_floor + nc) : zero4;
             {
                 const f32x16 a = acc[i][j];
                 SN_EPI_W(0); SN_EPI_W(1); SN_EPI_W(2); SN_EPI_W(3); SN_EPI_W(4); SN_EPI_W(5); SN_EPI_W(6); SN_EPI_W(7);
@@ -124,7 +126,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvA
                     v.x = __builtin_fmaf(v.x, os.x, ob.x); v.y = __builtin_fmaf(v.y, os.y, ob.y);
                     v.z = __builtin_fmaf(v.z, os.z, ob.z); v.w = __builtin_fmaf(v.w, os.w, ob.w);
                 }
-                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (has_floor) { v.x = fmaxf(v.x, fl.x); v.y = fmaxf(v.y, fl.y); v.z = fmaxf(v.z, fl.z); v.w = fmaxf(v.w, fl.w); }
+                else if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (!(CONV_ABLATE & 4)) {
                     if (ncol && mrow[q] < p.M) *reinterpret_cast<float4*>(outp + ((size_t)mrow[q] * p.Cout + n)) = v;
                 } else if (v.x == 123.456f) outp[0] = v.x;

@@ -68,8 +68,9 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
 
     // ---- DMA lane roles: instruction g in {wave, wave + 4} covers tile rows 8g .. 8g+7
     const int rr = lane >> 3, cp = lane & 7;
-    const int pad_off = (p.pad * p.W + p.pad) * p.Cin;
-    const int row_jump = (p.W - p.KW) * p.Cin;
+    const int ld = p.x_ld;                                  // floats between consecutive pixels of x (>= Cin)
+    const int pad_off = (p.pad * p.W + p.pad) * ld;
+    const int row_jump = (p.W - p.KW) * ld;
     const float* const zero_page = g_conv_zero_page;
 
     // ---- producer state: the tile whose stages are being issued
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
                 const int r = mc - img * (p.Ho * p.Wo);
                 const int oy = sn_fastdiv(r, p.div_w_mul, p.div_w_shift), ox = r - oy * p.Wo;
                 const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-                a_voff[t] = 4u * (unsigned)(((img * p.H + iy0 + p.pad) * p.W + ix0 + p.pad) * p.Cin + cl * 4);
+                a_voff[t] = 4u * (unsigned)(((img * p.H + iy0 + p.pad) * p.W + ix0 + p.pad) * ld + cl * 4);
                 unsigned long long mk = 0;
                 if (MODE == 1 && m < p.M) {
                     // taps (kh, kw) in frame: kh in [kh_lo, kh_hi), kw in [kw_lo, kw_hi): a run of KW-bit row patterns
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
             l_c0 = (ks_begin - l_tap * cin_steps) * BK;
             const int l_kh = l_tap / p.KW;
             l_kw = l_tap - l_kh * p.KW;
-            xb = p.x + ((l_kh * p.W + l_kw) * p.Cin + l_c0 - pad_off);
+            xb = p.x + ((l_kh * p.W + l_kw) * ld + l_c0 - pad_off);
             wb = p.w + (l_tap * p.Cin + l_c0);
         }
     };
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         if (l_c0 == p.Cin) {
             l_c0 = 0;
             ++l_tap;
+            xb += ld - p.Cin;                              // next tap = next pixel (0 for a dense tensor)
             if (++l_kw == p.KW) { l_kw = 0; xb += row_jump; }
         }
     };

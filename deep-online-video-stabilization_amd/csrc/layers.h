@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+int launch_merge_vectors(const float* b_sc, const float* scale1, const float* shift1, int depth, int dbn, float* out,
+                         hipStream_t st);
 int launch_stem_repack(const float* w, float* out, int Cout, int KH, int KW, int CinPad, int Cin, hipStream_t st);
 int launch_pad_channels(const float* x, float* y, long npix, int C, int Cp, hipStream_t st);
 int launch_max_pool(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, int k, int stride, int pt,

@@ -167,6 +167,27 @@ int launch_stem_repack(const float* w, float* out, int Cout, int KH, int KW, int
     return STABNET_OK;
 }
 
+// Per-channel epilogue vectors of a merged (shortcut | conv1) launch, out = [bias | scale | shift | floor], each depth + dbn:
+// shortcut channels: + bias, identity scale, no activation (floor = -inf); conv1 channels: folded bn1 + ReLU (floor = 0).
+__global__ __launch_bounds__(256) void merge_vectors_kernel(const float* __restrict__ b_sc, const float* __restrict__ scale1,
+                                                            const float* __restrict__ shift1, int depth, int dbn,
+                                                            float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x, Ct = depth + dbn;
+    if (c >= Ct) return;
+    const bool s = c < depth;
+    out[c] = s ? b_sc[c] : 0.f;
+    out[Ct + c] = s ? 1.f : scale1[c - depth];
+    out[2 * Ct + c] = s ? 0.f : shift1[c - depth];
+    out[3 * Ct + c] = s ? -INFINITY : 0.f;
+}
+
+int launch_merge_vectors(const float* b_sc, const float* scale1, const float* shift1, int depth, int dbn, float* out,
+                         hipStream_t st) {
+    merge_vectors_kernel<<<cdiv(depth + dbn, 256), 256, 0, st>>>(b_sc, scale1, shift1, depth, dbn, out);
+    SN_LAUNCH_CHECK("merge_vectors_kernel");
+    return STABNET_OK;
+}
+
 int launch_pad_channels(const float* x, float* y, long npix, int C, int Cp, hipStream_t st) {
     SN_REQUIRE(Cp % 4 == 0 && Cp >= C, "pad_channels: bad channel counts %d -> %d", C, Cp);
     pad_channels_kernel<<<cdiv(npix * (Cp / 4), 256), 256, 0, st>>>(x, y, npix, C, Cp);

@@ -39,6 +39,8 @@ struct Step {
     long in_off, out_off, res_off, w_off, b_off, bn_off;
     long obn_off;                                // inference only: folded BN + ReLU of the CONSUMER fused behind this conv
     int inf_preactivated;                        // inference only: the input tensor already holds relu(bn(.)) -> no prologue
+    long fvec_off;                               // inference only: per-channel (bias, scale, shift, floor) vectors of a merged
+                                                 // shortcut|conv1 launch, offset inside the merge region of `fold` (-1: none)
     int N, H, W, C, Ho, Wo, k, stride, pt, pl;   // pool / pad / gap
     int M, K, Nout, relu;                        // fc
     size_t splitk_bytes;
@@ -96,6 +98,9 @@ struct Net {
     int N, H, W, in_ch, in_ch_pad, n_theta, keep_all;
     int stem_rowrun = 0, in_ch_act = 0;            // inference plans read the 13-channel stack directly (ring kernel MODE 2)
     size_t stem_w_floats = 0;
+    struct MergeInfo { long off; int depth, dbn; long b_sc, bn1; };
+    std::vector<MergeInfo> merges;                // merged shortcut|conv1 launches of the inference plan
+    size_t merge_floats = 0;
     PackTable packs{};                            // dgrad weight re-pack of every unit conv (training)
     long pack_w3[16] = {0}, pack_w2[16] = {0}, pack_w1[16] = {0}, pack_sc[16] = {0};   // wt offsets per unit                     // re-laid-out stem weights [64][7][roundup(7*in_ch, 32)] behind the folded BN
     std::vector<UnitInfo> units;
@@ -172,7 +177,7 @@ static Step conv_step(Net& net, const TensorRef& in, const TensorRef& out, int K
     net.splitk_bytes = std::max(net.splitk_bytes, s.splitk_bytes);
     s.in_off = in.off; s.out_off = out.off; s.res_off = res ? res->off : NONE;
     s.w_off = w_off; s.b_off = b_off; s.bn_off = bn_off;
-    s.obn_off = NONE; s.inf_preactivated = 0;
+    s.obn_off = NONE; s.inf_preactivated = 0; s.fvec_off = NONE;
     net.flops += 2.0 * a.M * (double)(a.KH * a.KW * (real_cin ? real_cin : a.Cin)) * a.Cout;   // algorithmic (un-padded)
     return s;
 }
@@ -243,6 +248,8 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             const int Ho = (cur.H + 2 - 3) / stride + 1, Wo = (cur.W + 2 - 3) / stride + 1;
             TensorRef sc = cur;
             bool own_sc = false;
+            int merged_ld = 0;
+            TensorRef merged_buf{};
             // Inference plan, projection units (the first unit of every block): nothing reads the RAW unit input (the shortcut
             // is a conv of the pre-activation), so its producer -- the max-pool or the previous block's last conv3 -- applies
             // this unit's preact BN + ReLU itself and both convs of the unit run prologue-free on the ring kernel.
@@ -256,20 +263,40 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
                 st_.splitk_bytes = conv_plan(st_.conv);
                 net->splitk_bytes = std::max(net->splitk_bytes, st_.splitk_bytes);
             };
+            // Inference plan of a projection unit: shortcut (depth channels, bias) and conv1 (dbn channels, then bn1 + ReLU)
+            // are two 1x1 convolutions of the SAME activated input -> ONE launch with Cout = depth + dbn writing one buffer
+            // [M][depth + dbn] (weights adjacent in the parameter buffer; bias / BN scale / shift / activation floor per
+            // channel come from the fold buffer).  conv2 then reads its 64..512 channels with a pixel stride of depth + dbn,
+            // conv3 reads the residual with that row stride.
+            const bool merged = pre_act;
+            TensorRef r1;
             if (cin != b.depth) {       // projection shortcut: conv1x1(preact) + bias, stride 1 here
-                sc = new_tensor(ar, N, cur.H, cur.W, b.depth);
                 own_sc = true;
                 const long w = (long)net->add_param(S + "shortcut/weights", PK_CONV_W, b.depth, 1, 1, cin, cin);
+                const long w1 = (long)net->add_param(S + "conv1/weights", PK_CONV_W, b.dbn, 1, 1, cin, cin);   // adjacent to w
                 const long bb = (long)net->add_param(S + "shortcut/biases", PK_BIAS, b.depth, 0, 0, 0, 0);
-                net->steps.push_back(conv_step(*net, cur, sc, 1, 1, 0, w, bb, bn_pre, nullptr, 1));
-                if (pre_act) mark_preactivated(net->steps.back());
-                ui.w_sc = w; ui.b_sc = bb;
-            }
-            TensorRef r1 = new_tensor(ar, N, cur.H, cur.W, b.dbn);
-            {
+                ui.w_sc = w; ui.b_sc = bb; ui.w1 = w1;
+                if (merged) {
+                    const int Ct = b.depth + b.dbn;
+                    TensorRef xs = new_tensor(ar, N, cur.H, cur.W, Ct);
+                    net->steps.push_back(conv_step(*net, cur, xs, 1, 1, 0, w, NONE, bn_pre, nullptr, 1));
+                    mark_preactivated(net->steps.back());
+                    net->steps.back().fvec_off = (long)net->merge_floats;             // relative to the merge region of `fold`
+                    net->merges.push_back({(long)net->merge_floats, b.depth, b.dbn, bb, -1});
+                    net->merge_floats += (size_t)4 * Ct;
+                    sc = xs; sc.C = b.depth;                                   // views of the shared buffer (row stride Ct)
+                    r1 = xs; r1.off = xs.off + b.depth; r1.C = b.dbn;
+                    merged_ld = Ct; merged_buf = xs;
+                } else {
+                    sc = new_tensor(ar, N, cur.H, cur.W, b.depth);
+                    net->steps.push_back(conv_step(*net, cur, sc, 1, 1, 0, w, bb, bn_pre, nullptr, 1));
+                    r1 = new_tensor(ar, N, cur.H, cur.W, b.dbn);
+                    net->steps.push_back(conv_step(*net, cur, r1, 1, 1, 0, w1, NONE, bn_pre, nullptr, 1));
+                }
+            } else {
+                r1 = new_tensor(ar, N, cur.H, cur.W, b.dbn);
                 const long w = (long)net->add_param(S + "conv1/weights", PK_CONV_W, b.dbn, 1, 1, cin, cin);
                 net->steps.push_back(conv_step(*net, cur, r1, 1, 1, 0, w, NONE, bn_pre, nullptr, 1));
-                if (pre_act) mark_preactivated(net->steps.back());
                 ui.w1 = w;
             }
             const size_t i_conv1 = net->steps.size() - 1;
@@ -279,16 +306,18 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             {
                 const long w = (long)net->add_param(S + "conv2/weights", PK_CONV_W, b.dbn, 3, 3, b.dbn, b.dbn);
                 net->steps.push_back(conv_step(*net, r1, r2, 3, stride, 1, w, NONE, bn1, nullptr, 1));
+                if (merged_ld) net->steps.back().conv.x_ld = merged_ld;
                 ui.w2 = w;
             }
-            done(r1);
+            if (!merged_ld) done(r1);
             const size_t i_conv2 = net->steps.size() - 1;
             const long bn2 = net->add_bn(S + "conv2/BatchNorm", b.dbn);
             // Inference plan: conv1 and conv2 apply their consumer's folded BN + ReLU in the epilogue, so conv2 and conv3
             // read activated tensors and run prologue-free (LDS-DMA ring kernel).  Same arithmetic per element
             // (fma + max), applied once per activation instead of once per use.  Training keeps the raw conv outputs
             // (the batch statistics are taken over them).
-            net->steps[i_conv1].obn_off = bn1;
+            if (!merged_ld) net->steps[i_conv1].obn_off = bn1;
+            else net->merges.back().bn1 = bn1;
             net->steps[i_conv2].obn_off = bn2;
             net->steps[i_conv2].inf_preactivated = 1;
             if (!keep_all) {            // inference plan: conv2 runs prologue-free (ring kernel) -> its own split-K choice
@@ -304,6 +333,7 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
                 const long bb = (long)net->add_param(S + "conv3/biases", PK_BIAS, b.depth, 0, 0, 0, 0);
                 // identity shortcut of a strided unit = subsample(x, stride): read the residual at (oy*s, ox*s)
                 net->steps.push_back(conv_step(*net, r2, nxt, 1, 1, 0, w, bb, bn2, &sc, own_sc ? 1 : stride));
+                if (merged_ld) net->steps.back().conv.res_ld = merged_ld;
                 net->steps.back().inf_preactivated = 1;
                 if (!keep_all) {
                     Step& c3 = net->steps.back();
@@ -320,7 +350,8 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             net->max_w = std::max({net->max_w, (size_t)b.dbn * 9 * b.dbn, (size_t)b.depth * cin, (size_t)b.depth * b.dbn});
             net->max_c = std::max({net->max_c, (size_t)b.depth, (size_t)cin});
             done(r2);
-            if (own_sc) done(sc);
+            if (merged_ld) done(merged_buf);
+            else if (own_sc) done(sc);
             done(cur);
             cur = nxt;
             add_tap(*net, std::string(b.name) + "/unit_" + std::to_string(u), cur);
@@ -429,6 +460,11 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
                     a.out_scale = scale + s.obn_off;
                     a.out_shift = shift + s.obn_off;
                     a.relu_out = 1;
+                }
+                if (s.fvec_off >= 0) {                     // merged shortcut | conv1: everything per channel
+                    const float* v = fold + 2 * net->G + net->stem_w_floats + s.fvec_off;
+                    a.bias = v; a.out_scale = v + a.Cout; a.out_shift = v + 2 * a.Cout; a.out_floor = v + 3 * a.Cout;
+                    a.relu_out = 0;
                 }
                 a.partial = splitk;
                 rc = conv_launch(a, st, prof);
@@ -611,7 +647,13 @@ int stabnet_net_fold_bn(const void* netp, const float* params, float* fold, floa
     SN_REQUIRE(net && params && fold, "fold_bn: null pointer");
     int rc = launch_bn_fold(params + net->off_gamma, params + net->off_beta, params + net->off_mean,
                             params + net->off_var, eps, (int)net->G, fold, fold + net->G, (hipStream_t)stream);
-    if (rc || !net->stem_rowrun) return rc;
+    if (rc) return rc;
+    for (const Net::MergeInfo& m : net->merges) {          // per-channel epilogue vectors of the merged shortcut | conv1 launches
+        rc = launch_merge_vectors(params + m.b_sc, fold + m.bn1, fold + net->G + m.bn1, m.depth, m.dbn,
+                                  fold + 2 * net->G + net->stem_w_floats + m.off, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    if (!net->stem_rowrun) return STABNET_OK;
     // stem weights OHWI [64][7][7][in_ch_pad] -> row-run layout [64][7][roundup(7*in_ch, 32)] (zeros in the run padding)
     return launch_stem_repack(params + net->w_stem, fold + 2 * net->G, 64, 7, 7, net->in_ch_pad, net->in_ch,
                               (hipStream_t)stream);
@@ -620,7 +662,7 @@ int stabnet_net_fold_bn(const void* netp, const float* params, float* fold, floa
 /* Floats of the `fold` buffer: [G scales][G shifts][re-laid-out stem weights of an inference plan]. */
 size_t stabnet_net_fold_floats(const void* netp) {
     const Net* net = static_cast<const Net*>(netp);
-    return net ? 2 * net->G + net->stem_w_floats : 0;
+    return net ? 2 * net->G + net->stem_w_floats + net->merge_floats : 0;
 }
 
 /* get_resnet(x_tensor, is_training=False): x_tensor NHWC [N,H,W,in_ch] -> theta [N,n_theta]. */

@@ -59,8 +59,10 @@ def test_training_step_matches_autograd_oracle(cuda):
         n = int(np.prod([d for d in dims if d > 0]))
         gg, ww = got_flat[off:off + n], want_flat[off:off + n]
         # tensors whose gradient is analytically ~0 (e.g. a bias in front of a batch-stat BN) are judged against the
-        # global gradient scale instead of their own
-        scale = max(np.abs(ww).max(), 1e-5 * gmax)
+        # global gradient scale instead of their own.  (With a floor of 1e-5 * gmax the stem bias -- pure rounding noise,
+        # different from run to run because of the float atomics in wgrad -- measured 0.8e-2 .. 1.3e-2 over 8 runs against
+        # the 2e-2 bound and failed once in about a dozen; 1e-4 * gmax leaves a 10x margin.)
+        scale = max(np.abs(ww).max(), 1e-4 * gmax)
         err = np.abs(gg - ww).max() / scale
         worst = max(worst, err)
         assert err < 2e-2, "%s: rel err %g (scale %g)" % (name, err, scale)

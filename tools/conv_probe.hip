@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
     (void)hipMemset(x, 0, (size_t)N * H * W * Cin * 4); (void)hipMemset(w, 0, (size_t)Cout * KH * KH * Cin * 4);
     a.x = x; a.w = w; a.y = y; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KH; a.stride = 1; a.pad = pad;
     a.up = 1; a.Ho = H; a.Wo = W; a.res_H = H; a.res_W = W; a.res_stride = 1; a.M = N * H * W; a.K = KH * KH * Cin; a.splitk = 1;
+    a.x_ld = a.Cin; a.res_ld = a.Cout;
     sn_fastdiv_make((unsigned)(a.Ho * a.Wo), a.div_hw_mul, a.div_hw_shift); sn_fastdiv_make((unsigned)a.Wo, a.div_w_mul, a.div_w_shift);
     a.steps_per_split = KH * KH * (Cin / 32);
 #if PROBE_TILE == 0

@@ -19,6 +19,7 @@ int main(int argc, char** argv) {
     (void)hipMemset(x, 0, (size_t)(H + 8) * (W + 8) * Cin * 4 + 1024); (void)hipMemset(w, 0, (size_t)N * K * 4);
     a.x = x; a.w = w; a.y = y; a.N = 1; a.H = H; a.W = W; a.Cin = Cin; a.Cout = N; a.KH = KH; a.KW = KH; a.stride = st_; a.pad = KH / 2; a.rowrun = stem ? 1 : 0;
     a.up = 1; a.Ho = Ho; a.Wo = Wo; a.res_H = Ho; a.res_W = Wo; a.res_stride = 1; a.M = M; a.K = K; a.splitk = 1;
+    a.x_ld = a.Cin; a.res_ld = a.Cout;
     sn_fastdiv_make((unsigned)(a.Ho * a.Wo), a.div_hw_mul, a.div_hw_shift); sn_fastdiv_make((unsigned)a.Wo, a.div_w_mul, a.div_w_shift);
     a.steps_per_split = K / 32;
     dim3 grid((M + 63) / 64, (N + 63) / 64, 1);
