@@ -187,7 +187,8 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
     net->N = N; net->H = H; net->W = W; net->in_ch = in_ch; net->n_theta = n_theta; net->keep_all = keep_all;
     net->in_ch_pad = (in_ch + 15) / 16 * 16;
     static const int want_rowrun = []() { const char* v = getenv("STABNET_STEM_ROWRUN"); return v ? atoi(v) : 1; }();
-    net->stem_rowrun = (!keep_all && want_rowrun && 7 * in_ch <= 128) ? 1 : 0;
+    static const int want_ring = []() { const char* v = getenv("STABNET_CONV_RING"); return v ? atoi(v) : 1; }();   // (debug switch)
+    net->stem_rowrun = (!keep_all && want_rowrun && want_ring && 7 * in_ch <= 128) ? 1 : 0;
     net->in_ch_act = net->stem_rowrun ? in_ch : net->in_ch_pad;
     net->stem_w_floats = net->stem_rowrun ? (size_t)64 * 7 * 32 * ((7 * in_ch + 31) / 32) : 0;
     Arena ar;
@@ -253,7 +254,7 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             // Inference plan, projection units (the first unit of every block): nothing reads the RAW unit input (the shortcut
             // is a conv of the pre-activation), so its producer -- the max-pool or the previous block's last conv3 -- applies
             // this unit's preact BN + ReLU itself and both convs of the unit run prologue-free on the ring kernel.
-            const bool pre_act = !keep_all && cin != b.depth && !net->steps.empty() &&
+            const bool pre_act = !keep_all && want_ring && cin != b.depth && !net->steps.empty() &&
                                  (net->steps.back().kind == S_POOL || net->steps.back().kind == S_CONV) &&
                                  net->steps.back().out_off == cur.off && net->steps.back().obn_off < 0;
             if (pre_act) net->steps.back().obn_off = bn_pre;
