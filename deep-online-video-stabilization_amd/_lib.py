@@ -71,6 +71,13 @@ def check(rc: int, what: str = ""):
         raise StabnetError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
 
 
-def call(name: str, *args):
-    """Call an int-returning entry point and raise on a non-zero status."""
-    check(getattr(lib(), name)(*args), name)
+def call(name: str, *args, device=None):
+    """Call an int-returning entry point and raise on a non-zero status.  `device` (torch.device of the tensors whose
+    pointers are passed) makes that GPU current for the call: kernels launch on the CURRENT device, so a pointer of
+    cuda:1 handed over while cuda:0 is current would fault."""
+    fn = getattr(lib(), name)
+    if device is not None and device.type == "cuda":
+        with torch.cuda.device(device):
+            check(fn(*args), name)
+    else:
+        check(fn(*args), name)

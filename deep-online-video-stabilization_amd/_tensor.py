@@ -21,8 +21,9 @@ def ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
-def stream_ptr():
-    return torch.cuda.current_stream().cuda_stream
+def stream_ptr(device=None):
+    """Current torch stream OF `device` (a tensor's device), not of whichever GPU happens to be current."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def empty(shape, like: torch.Tensor, dtype=torch.float32):

@@ -29,4 +29,8 @@ void stabnet_set_error(const char* fmt, ...);
         }                                                                        \
     } while (0)
 
+// 0 when `p` is memory of the CURRENT device (the one kernels of this thread launch on); an error otherwise: a pointer of
+// another GPU passed with the wrong device current would fault inside a kernel instead.
+int sn_check_device(const void* p, const char* what, hipStream_t st = nullptr);   // (skipped while `st` is being captured)
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

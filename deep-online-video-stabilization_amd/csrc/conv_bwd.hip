@@ -8,8 +8,10 @@
 // wgrad tiling: the reduction runs over output pixels m, which is the slow index of both operands in memory
 // (dY[m][n], x[pix][c]), so tiles are staged in LDS as [pixel][64 channels] exactly as loaded and the MFMA operands
 // are read with ds_read_b32 (lane&31 -> consecutive channels: conflict-free).  Block = 64 output channels x 64
-// k-columns, 4 waves (32x32 each), 32 pixels per step, double-buffered; the M range is split over blockIdx.z and the
-// partial sums are accumulated with float atomics (dW is small; both towers of the siamese step add into it).
+// k-columns, 4 waves (32x32 each), 32 pixels per step, double-buffered; the M range is split over blockIdx.z.  Each split
+// writes its partial tile to its own SLAB with plain stores; wgrad_reduce_kernel then adds the slabs in split order and
+// accumulates into dW (both towers of the siamese step add into it, in stream order).  No float atomics: the step is
+// reproducible bit for bit, and plain stores run at ~5x the rate of memory-side float atomics (MI355X_MICROARCH.md).
 #include "conv.h"
 #include "prof.h"
 #include "train_layers.h"
@@ -20,7 +22,8 @@ typedef float f32x16w __attribute__((ext_vector_type(16)));
 struct WgradArgs {
     const float* x;          // forward input NHWC [N,H,W,Cin]
     const float* dy;         // output gradient NHWC [N,Ho,Wo,Cout]
-    float* dw;               // OHWI [Cout][KH][KW][Cin], accumulated into
+    float* dw;               // OHWI [Cout][KH][KW][Cin], accumulated into (only when slab == nullptr: one split)
+    float* slab;             // [splits][Cout][K] partial sums, or nullptr
     const float* in_scale;   // forward prologue (folded BN + ReLU) or null
     const float* in_shift;
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
@@ -133,7 +136,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs p) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = n0 + wn + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (n < p.Cout) atomicAdd(&p.dw[(size_t)n * p.K + k], acc[r]);
+            if (n >= p.Cout) continue;
+            if (p.slab != nullptr) p.slab[((size_t)blockIdx.z * p.Cout + n) * p.K + k] = acc[r];
+            else p.dw[(size_t)n * p.K + k] += acc[r];          // single split: this lane owns the element
         }
     }
 }
@@ -152,10 +157,60 @@ __global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(const float* __
     wt[q] = w[(((size_t)co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * Cin + ci];
 }
 
-int wgrad_launch(const float* x, const float* dy, float* dw, const float* in_scale, const float* in_shift, int N, int H,
-                 int W, int Cin, int Cout, int KH, int KW, int stride, int pad, hipStream_t st, Prof* prof) {
+// Split of the pixel range: ~1024 blocks in all, at least 256 pixels (8 steps) per block.
+int wgrad_splits(int Cout, int K, int M, int* rows_per_split) {
+    const int tiles = cdiv(Cout, 64) * cdiv(K, 64);
+    int splits = std::max(1, std::min(cdiv(1024, tiles), cdiv(M, 256)));
+    splits = std::min(splits, 65535);
+    const int rps = cdiv(cdiv(M, splits), 32) * 32;
+    if (rows_per_split) *rows_per_split = rps;
+    return cdiv(M, rps);
+}
+size_t wgrad_slab_floats(int Cout, int K, int M) {
+    const int s = wgrad_splits(Cout, K, M, nullptr);
+    return s > 1 ? (size_t)s * Cout * K : 0;
+}
+
+// dw += sum_z slab[z] (z ascending) for every entry of the table; one float4 per thread.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ grads, const float* __restrict__ slabs,
+                                                           const WgradReduceTable t) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;          // float4 index over all entries
+    if (q >= t.prefix[t.n]) return;
+    int lo = 0, hi = t.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.prefix[mid] <= q) lo = mid; else hi = mid - 1;
+    }
+    const WgradReduceEntry e = t.e[lo];
+    const long i = (q - t.prefix[lo]) * 4;
+    const float* s = slabs + e.slab_off + i;
+    float4 acc = *reinterpret_cast<const float4*>(s);
+    for (int z = 1; z < e.splits; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(s + (size_t)z * e.elems);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float4* d = reinterpret_cast<float4*>(grads + e.dw_off + i);
+    float4 o = *d;
+    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+    *d = o;
+}
+
+int wgrad_reduce_flush(float* grads, const float* slabs, WgradReduceTable& t, hipStream_t st) {
+    if (t.n == 0) return STABNET_OK;
+    wgrad_reduce_kernel<<<cdiv(t.prefix[t.n], 256), 256, 0, st>>>(grads, slabs, t);
+    SN_LAUNCH_CHECK("wgrad_reduce_kernel");
+    t.n = 0; t.prefix[0] = 0;
+    return STABNET_OK;
+}
+
+// dw_base + dw_off: where the gradient accumulates.  slab_base + *slab_cursor: this layer's slabs (the cursor advances);
+// the entry is appended to `table` and reduced by the next wgrad_reduce_flush.  table == nullptr (stand-alone use): the
+// reduce is launched here.
+int wgrad_launch(const float* x, const float* dy, float* dw_base, long dw_off, const float* in_scale, const float* in_shift,
+                 int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* slab_base,
+                 size_t* slab_cursor, WgradReduceTable* table, hipStream_t st, Prof* prof) {
     WgradArgs a{};
-    a.x = x; a.dy = dy; a.dw = dw; a.in_scale = in_scale; a.in_shift = in_shift;
+    a.x = x; a.dy = dy; a.dw = dw_base + dw_off; a.in_scale = in_scale; a.in_shift = in_shift;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.Ho = (H + 2 * pad - KH) / stride + 1;
     a.Wo = (W + 2 * pad - KW) / stride + 1;
@@ -163,16 +218,28 @@ int wgrad_launch(const float* x, const float* dy, float* dw, const float* in_sca
     a.K = KH * KW * Cin;
     SN_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "wgrad: channel counts must be multiples of 4");
     SN_REQUIRE((long)a.M * Cout < (1L << 31) && (long)N * H * W * Cin < (1L << 31), "wgrad: tensors must have < 2^31 elements");
-    const int tiles = cdiv(Cout, 64) * cdiv(a.K, 64);
-    int splits = std::max(1, std::min(cdiv(1024, tiles), cdiv(a.M, 256)));      // >= 256 pixels (8 steps) per block
-    splits = std::min(splits, 65535);
-    a.rows_per_split = cdiv(cdiv(a.M, splits), 32) * 32;
-    splits = cdiv(a.M, a.rows_per_split);
+    const int splits = wgrad_splits(Cout, a.K, a.M, &a.rows_per_split);
+    const size_t elems = (size_t)Cout * a.K;
+    WgradReduceTable local{};
+    if (splits > 1) {
+        SN_REQUIRE(slab_base != nullptr && slab_cursor != nullptr, "wgrad: %d splits need a slab workspace", splits);
+        a.slab = slab_base + *slab_cursor;
+        WgradReduceTable* t = table ? table : &local;
+        if (t->n == WGRAD_TABLE_MAX) {
+            int rc = wgrad_reduce_flush(dw_base, slab_base, *t, st);
+            if (rc) return rc;
+        }
+        t->e[t->n] = {dw_off, (long)*slab_cursor, (long)elems, splits};
+        t->prefix[t->n + 1] = t->prefix[t->n] + (long)(elems / 4);
+        ++t->n;
+        *slab_cursor += (size_t)splits * elems;
+    }
     const bool rec = prof != nullptr && prof->begin(st);
     conv_wgrad_f32_kernel<<<dim3(cdiv(Cout, 64), cdiv(a.K, 64), splits), 256, 0, st>>>(a);
     if (rec) prof->end(st, PK_KERNEL_WGRAD, 2.0 * a.M * (double)a.K * Cout,
                        4.0 * ((double)a.M * Cout + (double)N * H * W * Cin + (double)a.K * Cout * splits), Cout, a.K, a.M, splits);
     SN_LAUNCH_CHECK("conv_wgrad_f32_kernel");
+    if (splits > 1 && table == nullptr) return wgrad_reduce_flush(dw_base, slab_base, local, st);
     return STABNET_OK;
 }
 
@@ -235,12 +302,22 @@ int dgrad_launch(const float* dy, const float* wt, float* dx, const float* resid
 extern "C" {
 
 /* d conv2d / d weights, accumulated into dw (OHWI [Cout][KH][KW][Cin], NOT zeroed here).  x: the forward input,
- * (in_scale, in_shift): the forward's folded-BN + ReLU prologue (or NULL), dy [N,Ho,Wo,Cout]. */
+ * (in_scale, in_shift): the forward's folded-BN + ReLU prologue (or NULL), dy [N,Ho,Wo,Cout].
+ * workspace: stabnet_conv2d_wgrad_workspace_bytes() (per-split partial slabs; reduced in split order: reproducible). */
+size_t stabnet_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    return wgrad_slab_floats(Cout, KH * KW * Cin, N * Ho * Wo) * sizeof(float) + 16;
+}
 int stabnet_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* in_scale, const float* in_shift,
-                         int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+                         int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,
+                         size_t workspace_bytes, void* stream) {
     SN_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
     SN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad: in_scale and in_shift go together");
-    return wgrad_launch(x, dy, dw, in_scale, in_shift, N, H, W, Cin, Cout, KH, KW, stride, pad, (hipStream_t)stream, nullptr);
+    SN_REQUIRE(workspace != nullptr && workspace_bytes >= stabnet_conv2d_wgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad),
+               "conv2d_wgrad: workspace too small");
+    size_t cursor = 0;
+    return wgrad_launch(x, dy, dw, 0, in_scale, in_shift, N, H, W, Cin, Cout, KH, KW, stride, pad,
+                        static_cast<float*>(workspace), &cursor, nullptr, (hipStream_t)stream, nullptr);
 }
 
 /* d conv2d / d input: dx [N,H,W,Cin] (+ residual if given) from dy [N,Ho,Wo,Cout] and the forward weights

@@ -233,3 +233,33 @@ int launch_fc(const float* x, const float* w, const float* b, float* y, int M, i
     }
     return STABNET_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Small re-packing helpers of the host mirror (so that no tensor operation of the path runs outside the library):
+//   slice_channel : x [npix][C] -> out [npix] = x[:, c]        (x_tensor[..., 12:13], flow[..., 0])
+//   interleave2   : a, b [n]   -> out [n][2]                   (img = [x_map, y_map], spatial_transformer3.py:295)
+__global__ __launch_bounds__(256) void slice_channel_kernel(const float* __restrict__ x, long npix, int C, int c,
+                                                            float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < npix) out[i] = x[i * C + c];
+}
+__global__ __launch_bounds__(256) void interleave2_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                          float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) *reinterpret_cast<float2*>(out + 2 * i) = make_float2(a[i], b[i]);
+}
+
+extern "C" {
+int stabnet_slice_channel(const float* x, long npix, int C, int c, float* out, void* stream) {
+    SN_REQUIRE(x && out && npix > 0 && C > 0 && c >= 0 && c < C, "slice_channel: bad arguments");
+    slice_channel_kernel<<<cdiv(npix, 256), 256, 0, (hipStream_t)stream>>>(x, npix, C, c, out);
+    SN_LAUNCH_CHECK("slice_channel_kernel");
+    return STABNET_OK;
+}
+int stabnet_interleave2(const float* a, const float* b, long n, float* out, void* stream) {
+    SN_REQUIRE(a && b && out && n > 0, "interleave2: bad arguments");
+    interleave2_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(a, b, n, out);
+    SN_LAUNCH_CHECK("interleave2_kernel");
+    return STABNET_OK;
+}
+}

@@ -21,6 +21,8 @@
 #include "train_layers.h"
 #include "warp.h"
 
+extern "C" int stabnet_black_accumulate(const float* black, int* all_black, long n, void* stream);
+
 enum { PK_CONV_W = 0, PK_BIAS = 1, PK_GAMMA = 2, PK_BETA = 3, PK_MEAN = 4, PK_VAR = 5, PK_FC_W = 6, PK_FC_B = 7 };
 enum { S_PAD = 0, S_CONV = 1, S_POOL = 2, S_GAP = 3, S_FC = 4 };
 static const long EXT_IN = -2, EXT_OUT = -3, NONE = -1;
@@ -444,7 +446,7 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
         const bool rec = (s.kind != S_CONV) && prof != nullptr && prof->begin(st);
         switch (s.kind) {
             case S_PAD:
-                if (net->stem_rowrun) rc = launch_embed_border(x, s.N, s.H, s.W, s.C, 3, ws + s.out_off, st);
+                if (net->stem_rowrun) rc = launch_embed_border(x, s.N, s.H, s.W, s.C, 3, ws + s.out_off, st);   // (+ the slack row)
                 else rc = launch_pad_channels(x, ws + s.out_off, (long)s.N * s.H * s.W, s.C, net->in_ch_act, st);
                 break;
             case S_CONV: {
@@ -676,6 +678,9 @@ int stabnet_backbone_fwd_infer(const void* netp, const float* params, const floa
                           stabnet_net_workspace_bytes(netp));
         return STABNET_ERR_WORKSPACE;
     }
+    int rc = sn_check_device(params, "backbone_fwd_infer: params", (hipStream_t)stream);
+    if (rc == 0) rc = sn_check_device(x_tensor, "backbone_fwd_infer: x_tensor", (hipStream_t)stream);
+    if (rc) return rc;
     return run_forward(net, params, fold, x_tensor, theta, static_cast<float*>(workspace), (hipStream_t)stream,
                        static_cast<Prof*>(prof));
 }
@@ -690,14 +695,16 @@ int stabnet_ring_init(float* frames_ring, float* masks_ring, const float* first_
 
 /* One iteration of the online loop for S = net.N independent streams (deploy_bundle.py:259-296,319-332):
  * stack assembly from the ring -> regressor -> get_4_pts + transformer -> frame = img - black -> push.
- * `head` (DEVICE int) = ring slot this frame's push writes; the call advances it, (head+1) % depth, with a one-thread
- * kernel at the end, so the whole frame has fixed arguments and can be captured once into a hipGraph and replayed.
- * `lags` is a HOST array (read at enqueue time). */
+ * `head` (DEVICE int[2]) = {ring slot this frame's push writes, ticket counter (zero)}; the call advances head[0] to
+ * (head+1) % depth on the device (last block of the sampler for refine = 1, a one-thread kernel otherwise), so the
+ * whole frame has fixed arguments and can be captured once into a hipGraph and replayed.
+ * `lags` is a HOST array (read at enqueue time).  all_black (optional, int32 [S][H*W]) += round(black) once per refine
+ * pass (deploy_bundle.py:291 sits inside the refine loop). */
 int stabnet_deploy_frame(const void* netp, const float* params, const float* fold, float* frames_ring,
                          float* masks_ring, int depth, int* head, const int* lags, int n_lags, const float* cur_frame,
                          int refine, int grid_h, int grid_w, float do_crop_rate, float* theta, float* out_img,
-                         float* black, float* x_map, float* y_map, float* Hs, float* frame_fb, void* workspace,
-                         size_t workspace_bytes, void* stream, void* profp) {
+                         float* black, float* x_map, float* y_map, float* Hs, float* frame_fb, int* all_black,
+                         void* workspace, size_t workspace_bytes, void* stream, void* profp) {
     const Net* net = static_cast<const Net*>(netp);
     SN_REQUIRE(net && params && fold && frames_ring && masks_ring && lags && cur_frame && theta && out_img && black &&
                    x_map && y_map && Hs && frame_fb && workspace, "deploy_frame: null pointer");
@@ -711,6 +718,8 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
     }
     int rc = check_warp_args(net->N, net->H, net->W, 1, grid_h, grid_w);
     if (rc) return rc;
+    if ((rc = sn_check_device(params, "deploy_frame: params", (hipStream_t)stream)) != 0) return rc;
+    if ((rc = sn_check_device(workspace, "deploy_frame: workspace", (hipStream_t)stream)) != 0) return rc;
     hipStream_t st = (hipStream_t)stream;
     Prof* prof = static_cast<Prof*>(profp);
     float* ws = static_cast<float*>(workspace);
@@ -723,6 +732,7 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
     const long hw = (long)net->H * net->W;
     const float* cur = cur_frame;
     float* x16 = ws + net->steps[0].out_off;
+    const bool fused_push = (refine == 1) && (net->W % 4 == 0);
     for (int j = 0; j < refine; ++j) {
         bool rec = prof && prof->begin(st);
         if (net->stem_rowrun)
@@ -737,11 +747,20 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
         rc = launch_mesh(theta, 1, net->N, grid_h, grid_w, 1.0f / do_crop_rate, nullptr, Hs, st);
         if (rec) prof->end(st, PK_KERNEL_MESH, 0, 4.0 * net->N * (net->n_theta + grid_h * grid_w * 9));
         if (rc) return rc;
-        rec = prof && prof->begin(st);
         // the frame being warped is the (possibly refined) current frame: channel 2*n_lags of the stack
+        if (fused_push) {
+            // sampler + frame = img - black + push into the ring + all_black + head advance: ONE launch
+            WarpPush wp{frames_ring, masks_ring, frame_fb, all_black, head, head, head + 1, depth};
+            rec = prof && prof->begin(st);
+            rc = launch_sample_push(Hs, cur, net->N, net->H, net->W, grid_h, grid_w, out_img, black, x_map, y_map, wp, st);
+            if (rec) prof->end(st, PK_KERNEL_WARP, 0, net->N * (32.0 * hw + 776.0) + (all_black ? 8.0 * net->N * hw : 0.0));
+            return rc;
+        }
+        rec = prof && prof->begin(st);
         rc = launch_sample(Hs, cur, net->N, net->H, net->W, 1, grid_h, grid_w, out_img, black, x_map, y_map, st);
         if (rec) prof->end(st, PK_KERNEL_WARP, 0, net->N * (20.0 * hw + 776.0));
         if (rc) return rc;
+        if (all_black != nullptr && (rc = stabnet_black_accumulate(black, all_black, (long)net->N * hw, stream)) != 0) return rc;
         // frame = img - black; with refine > 1 it replaces the current frame of the next pass (:293-295)
         const bool last = (j == refine - 1);
         rec = prof && prof->begin(st);
@@ -764,8 +783,8 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
 // train_bundle_nobm.py:155-160).  The plan must have been created with keep_activations = 1.
 // =========================================================================================================
 struct TrainLayout {
-    size_t bn_scale, bn_shift, bn_mean, bn_invstd, GA, GB, T1, T2, T3, fcg0, fcg1, partial, coef, wt, argmax, splitk, total;
-    size_t splitk_bytes;
+    size_t bn_scale, bn_shift, bn_mean, bn_invstd, GA, GB, T1, T2, T3, fcg0, fcg1, partial, coef, wt, argmax, splitk, slabs, total;
+    size_t splitk_bytes, slab_floats;
 };
 
 static size_t rnd64(size_t n) { return (n + 63) & ~(size_t)63; }
@@ -805,6 +824,17 @@ static TrainLayout train_layout(const Net* net) {
     }
     L.splitk_bytes = sk;
     L.splitk = take(sk / sizeof(float) + 64);
+    // wgrad partial slabs of every conv of one backward (consumed stage by stage by wgrad_reduce_flush)
+    size_t sl = 0;
+    for (const UnitInfo& u : net->units) {
+        sl += wgrad_slab_floats(u.depth, u.dbn, u.out.N * u.out.H * u.out.W);
+        sl += wgrad_slab_floats(u.dbn, 9 * u.dbn, u.r2.N * u.r2.H * u.r2.W);
+        sl += wgrad_slab_floats(u.dbn, u.cin, u.x.N * u.x.H * u.x.W);
+        if (u.proj) sl += wgrad_slab_floats(u.depth, u.cin, u.x.N * u.x.H * u.x.W);
+    }
+    sl += wgrad_slab_floats(64, 49 * net->in_ch_pad, net->t_c1.N * net->t_c1.H * net->t_c1.W);
+    L.slab_floats = sl;
+    L.slabs = take(sl + 64);
     L.total = o;
     return L;
 }
@@ -869,8 +899,21 @@ static int run_forward_train(const Net* net, float* params, const float* x, floa
     return STABNET_OK;
 }
 
-static int run_backward(const Net* net, const float* params, const float* d_theta, float* grads, float* ws,
-                        hipStream_t st, Prof* prof) {
+// Backward in STAGES so that a data-parallel host can hand each parameter bucket to the collective while the earlier
+// layers are still in backward (reverse layer order).  stage 0 = FC head + postnorm + block4, 1 = block3,
+// 2 = block2, 3 = block1 + stem.  A stage leaves d(unit input) in GA/GB (which one: parity of the units processed) and
+// ends with the ordered reduction of its wgrad slabs, so its gradients are final when the stage's kernels are done.
+static const int kNumStages = 4;
+static void stage_units(const Net* net, int stage, int& u_hi, int& u_lo) {      // units [u_lo, u_hi] processed descending
+    // blocks of resnet_v2_50: 3, 4, 6, 3 units
+    const int first[5] = {0, 3, 7, 13, 16};
+    const int blk = 3 - stage;
+    u_lo = first[blk]; u_hi = first[blk + 1] - 1;
+    (void)net;
+}
+
+static int run_backward_stage(const Net* net, const float* params, const float* d_theta, float* grads, float* ws, int stage,
+                              hipStream_t st, Prof* prof) {
     const TrainLayout L = train_layout(net);
     const float* scale = ws + L.bn_scale;
     const float* shift = ws + L.bn_shift;
@@ -880,59 +923,80 @@ static int run_backward(const Net* net, const float* params, const float* d_thet
     float* coef = ws + L.coef;
     float* wt = ws + L.wt;
     float* splitk = ws + L.splitk;
+    float* slabs = ws + L.slabs;
     const int N = net->N;
     int rc;
+    SN_REQUIRE(net->units.size() == 16, "tower_bwd: unexpected unit count %zu", net->units.size());
+    WgradReduceTable table{};
+    // slab cursor at the start of this stage = slab floats of the stages before it (layers are visited in a fixed order)
+    size_t cursor = 0;
+    auto unit_slabs = [&](const UnitInfo& u) {
+        size_t n = wgrad_slab_floats(u.depth, u.dbn, u.out.N * u.out.H * u.out.W) + wgrad_slab_floats(u.dbn, 9 * u.dbn, u.r2.N * u.r2.H * u.r2.W) +
+                   wgrad_slab_floats(u.dbn, u.cin, u.x.N * u.x.H * u.x.W);
+        if (u.proj) n += wgrad_slab_floats(u.depth, u.cin, u.x.N * u.x.H * u.x.W);
+        return n;
+    };
+    for (int sg = 0; sg < stage; ++sg) {
+        int hi, lo;
+        stage_units(net, sg, hi, lo);
+        for (int ui = hi; ui >= lo; --ui) cursor += unit_slabs(net->units[ui]);
+    }
+    auto wgrad = [&](const float* x, const float* dy, long w_off, const float* sc, const float* sh, int H, int W, int Cin, int Cout,
+                     int K, int stride, int pad) -> int {
+        return wgrad_launch(x, dy, grads, w_off, sc, sh, N, H, W, Cin, Cout, K, K, stride, pad, slabs, &cursor, &table, st, prof);
+    };
     auto bn_bwd = [&](long bn, const TensorRef& xt, const float* g, const float* addend, int add_stride, float* dx) -> int {
         return launch_bn_relu_bwd(ws + xt.off, g, scale + bn, shift + bn, bmean + bn, binv + bn, params + net->off_gamma + bn,
                                   (long)xt.N * xt.H * xt.W, xt.C, addend, add_stride, xt.H, xt.W, grads + net->off_gamma + bn,
                                   grads + net->off_beta + bn, dx, partial, coef, st);
     };
-    if ((rc = pack_dgrad_weights_all(params, wt, net->packs, st)) != 0) return rc;
-    // ---- FC head (resnet.py:44-56, s_net_bundle_nobm.py:256-259)
-    float* fg[2] = {ws + L.fcg0, ws + L.fcg1};
-    const TensorRef* fin[4] = {&net->t_gap, &net->t_fc[0], &net->t_fc[1], &net->t_fc[2]};
-    const float* dy = d_theta;
-    for (int k = 3; k >= 0; --k) {
-        const float* yk = (k < 3) ? ws + net->t_fc[k].off : nullptr;            // output of layer k (ReLU mask), k < 3
-        float* dx = fg[k & 1];
-        rc = launch_fc_bwd(ws + fin[k]->off, params + net->fc_w[k], yk, dy, N, net->fc_dims[k], net->fc_dims[k + 1], k < 3,
-                           grads + net->fc_w[k], grads + net->fc_b[k], dx, st);
-        if (rc) return rc;
-        dy = dx;
-    }
-    // ---- reduce_mean + postnorm BN + ReLU
     float* GA = ws + L.GA;
     float* GB = ws + L.GB;
     float* T1 = ws + L.T1;
     float* T2 = ws + L.T2;
     float* T3 = ws + L.T3;
-    const TensorRef& last = net->t_last;
-    if ((rc = launch_gap_bwd(dy, N, last.H * last.W, last.C, T3, st)) != 0) return rc;
-    if ((rc = bn_bwd(net->bn_post, last, T3, nullptr, 1, GA)) != 0) return rc;
-    // ---- bottleneck units, last to first.  G = d(unit output)
-    for (int ui = (int)net->units.size() - 1; ui >= 0; --ui) {
+    int u_hi, u_lo;
+    stage_units(net, stage, u_hi, u_lo);
+    if ((15 - u_hi) & 1) std::swap(GA, GB);               // one swap per unit already processed
+    if (stage == 0) {
+        if ((rc = pack_dgrad_weights_all(params, wt, net->packs, st)) != 0) return rc;
+        // ---- FC head (resnet.py:44-56, s_net_bundle_nobm.py:256-259)
+        float* fg[2] = {ws + L.fcg0, ws + L.fcg1};
+        const TensorRef* fin[4] = {&net->t_gap, &net->t_fc[0], &net->t_fc[1], &net->t_fc[2]};
+        const float* dy = d_theta;
+        for (int k = 3; k >= 0; --k) {
+            const float* yk = (k < 3) ? ws + net->t_fc[k].off : nullptr;            // output of layer k (ReLU mask), k < 3
+            float* dx = fg[k & 1];
+            rc = launch_fc_bwd(ws + fin[k]->off, params + net->fc_w[k], yk, dy, N, net->fc_dims[k], net->fc_dims[k + 1], k < 3,
+                               grads + net->fc_w[k], grads + net->fc_b[k], dx, st);
+            if (rc) return rc;
+            dy = dx;
+        }
+        // ---- reduce_mean + postnorm BN + ReLU
+        const TensorRef& last = net->t_last;
+        if ((rc = launch_gap_bwd(dy, N, last.H * last.W, last.C, T3, st)) != 0) return rc;
+        if ((rc = bn_bwd(net->bn_post, last, T3, nullptr, 1, GA)) != 0) return rc;
+    }
+    // ---- bottleneck units of this stage, last to first.  G = d(unit output)
+    for (int ui = u_hi; ui >= u_lo; --ui) {
         const UnitInfo& u = net->units[ui];
         const long Mo = (long)u.out.N * u.out.H * u.out.W;
         float* G = GA;
         // conv3 (1x1, bias) : input relu(bn2(r2))
         if ((rc = launch_bias_grad(G, Mo, u.depth, grads + u.b3, partial, st)) != 0) return rc;
-        if ((rc = wgrad_launch(ws + u.r2.off, G, grads + u.w3, scale + u.bn2, shift + u.bn2, N, u.r2.H, u.r2.W, u.dbn, u.depth,
-                               1, 1, 1, 0, st, prof)) != 0) return rc;
+        if ((rc = wgrad(ws + u.r2.off, G, u.w3, scale + u.bn2, shift + u.bn2, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0)) != 0) return rc;
         if ((rc = dgrad_launch(G, wt + net->pack_w3[ui], T1, nullptr, N, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
         if ((rc = bn_bwd(u.bn2, u.r2, T1, nullptr, 1, T1)) != 0) return rc;                      // T1 = d r2
         // conv2 (3x3, stride) : input relu(bn1(r1))
-        if ((rc = wgrad_launch(ws + u.r1.off, T1, grads + u.w2, scale + u.bn1, shift + u.bn1, N, u.r1.H, u.r1.W, u.dbn, u.dbn,
-                               3, 3, u.stride, 1, st, prof)) != 0) return rc;
+        if ((rc = wgrad(ws + u.r1.off, T1, u.w2, scale + u.bn1, shift + u.bn1, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, u.stride, 1)) != 0) return rc;
         if ((rc = dgrad_launch(T1, wt + net->pack_w2[ui], T2, nullptr, N, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, 3, u.stride, 1, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
         if ((rc = bn_bwd(u.bn1, u.r1, T2, nullptr, 1, T2)) != 0) return rc;                      // T2 = d r1
         // conv1 (1x1) : input relu(bn_pre(x))
-        if ((rc = wgrad_launch(ws + u.x.off, T2, grads + u.w1, scale + u.bn_pre, shift + u.bn_pre, N, u.x.H, u.x.W, u.cin, u.dbn,
-                               1, 1, 1, 0, st, prof)) != 0) return rc;
+        if ((rc = wgrad(ws + u.x.off, T2, u.w1, scale + u.bn_pre, shift + u.bn_pre, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 0)) != 0) return rc;
         if ((rc = dgrad_launch(T2, wt + net->pack_w1[ui], T3, nullptr, N, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
         if (u.proj) {   // projection shortcut conv1x1(preact) + bias: d preact += dgrad(G)
             if ((rc = launch_bias_grad(G, Mo, u.depth, grads + u.b_sc, partial, st)) != 0) return rc;
-            if ((rc = wgrad_launch(ws + u.x.off, G, grads + u.w_sc, scale + u.bn_pre, shift + u.bn_pre, N, u.x.H, u.x.W, u.cin,
-                                   u.depth, 1, 1, 1, 0, st, prof)) != 0) return rc;
+            if ((rc = wgrad(ws + u.x.off, G, u.w_sc, scale + u.bn_pre, shift + u.bn_pre, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 0)) != 0) return rc;
             if ((rc = dgrad_launch(G, wt + net->pack_sc[ui], T3, T3, N, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
             if ((rc = bn_bwd(u.bn_pre, u.x, T3, nullptr, 1, GB)) != 0) return rc;
         } else {        // identity shortcut (subsample by the unit's stride): d x += upsample(G)
@@ -940,14 +1004,17 @@ static int run_backward(const Net* net, const float* params, const float* d_thet
         }
         std::swap(GA, GB);
     }
-    // ---- stem: max-pool backward, conv1 weight/bias gradient (the input needs no gradient)
-    const TensorRef& c1 = net->t_c1;
-    const TensorRef& pl = net->t_pool;
-    if ((rc = launch_max_pool_bwd(reinterpret_cast<const unsigned char*>(ws + L.argmax), GA, GB, N, c1.H, c1.W, c1.C, pl.H, pl.W,
-                                  3, 2, net->pool_pt, net->pool_pl, st)) != 0) return rc;
-    if ((rc = launch_bias_grad(GB, (long)N * c1.H * c1.W, 64, grads + net->b_stem, partial, st)) != 0) return rc;
-    return wgrad_launch(ws + net->t_xin.off, GB, grads + net->w_stem, nullptr, nullptr, N, net->H, net->W, net->in_ch_pad, 64, 7,
-                        7, 2, 3, st, prof);
+    if (stage == kNumStages - 1) {
+        // ---- stem: max-pool backward, conv1 weight/bias gradient (the input needs no gradient)
+        const TensorRef& c1 = net->t_c1;
+        const TensorRef& pl = net->t_pool;
+        if ((rc = launch_max_pool_bwd(reinterpret_cast<const unsigned char*>(ws + L.argmax), GA, GB, N, c1.H, c1.W, c1.C, pl.H, pl.W,
+                                      3, 2, net->pool_pt, net->pool_pl, st)) != 0) return rc;
+        if ((rc = launch_bias_grad(GB, (long)N * c1.H * c1.W, 64, grads + net->b_stem, partial, st)) != 0) return rc;
+        if ((rc = wgrad(ws + net->t_xin.off, GB, net->w_stem, nullptr, nullptr, net->H, net->W, net->in_ch_pad, 64, 7, 2, 3)) != 0) return rc;
+    }
+    SN_REQUIRE(cursor <= L.slab_floats, "tower_bwd: slab workspace overrun (%zu > %zu)", cursor, L.slab_floats);
+    return wgrad_reduce_flush(grads, slabs, table, st);
 }
 
 extern "C" {
@@ -967,20 +1034,65 @@ int stabnet_tower_fwd_train(const void* netp, float* params, const float* x_tens
     SN_REQUIRE(net && params && x_tensor && theta && workspace, "tower_fwd_train: null pointer");
     SN_REQUIRE(net->keep_all, "tower_fwd_train: the plan must be created with keep_activations = 1");
     SN_REQUIRE(workspace_bytes >= stabnet_net_train_workspace_bytes(netp), "tower_fwd_train: workspace too small");
+    if (int rc = sn_check_device(params, "tower_fwd_train: params", (hipStream_t)stream)) return rc;
+    if (int rc = sn_check_device(x_tensor, "tower_fwd_train: x_tensor", (hipStream_t)stream)) return rc;
     return run_forward_train(net, params, x_tensor, theta, static_cast<float*>(workspace), bn_eps, bn_decay,
                              (hipStream_t)stream, static_cast<Prof*>(prof));
 }
 
 /* Backward of the tower given d_theta [N,n_theta]; gradients are ACCUMULATED into `grads` (same layout as the
- * trainable prefix of `params`; zero it once per step -- both siamese towers add into it). */
-int stabnet_tower_bwd(const void* netp, const float* params, const float* d_theta, float* grads, void* workspace,
-                      size_t workspace_bytes, void* stream, void* prof) {
-    const Net* net = static_cast<const Net*>(netp);
+ * trainable prefix of `params`; zero it once per step -- both siamese towers add into it, in stream order). */
+static int tower_bwd_checks(const Net* net, const float* params, const float* d_theta, float* grads, void* workspace,
+                            size_t workspace_bytes, const void* netp, void* stream) {
     SN_REQUIRE(net && params && d_theta && grads && workspace, "tower_bwd: null pointer");
     SN_REQUIRE(net->keep_all, "tower_bwd: the plan must be created with keep_activations = 1");
     SN_REQUIRE(workspace_bytes >= stabnet_net_train_workspace_bytes(netp), "tower_bwd: workspace too small");
-    return run_backward(net, params, d_theta, grads, static_cast<float*>(workspace), (hipStream_t)stream,
-                        static_cast<Prof*>(prof));
+    return sn_check_device(grads, "tower_bwd: grads", (hipStream_t)stream);
+}
+int stabnet_tower_bwd(const void* netp, const float* params, const float* d_theta, float* grads, void* workspace,
+                      size_t workspace_bytes, void* stream, void* prof) {
+    const Net* net = static_cast<const Net*>(netp);
+    int rc = tower_bwd_checks(net, params, d_theta, grads, workspace, workspace_bytes, netp, stream);
+    for (int stage = 0; rc == 0 && stage < kNumStages; ++stage)
+        rc = run_backward_stage(net, params, d_theta, grads, static_cast<float*>(workspace), stage, (hipStream_t)stream,
+                                static_cast<Prof*>(prof));
+    return rc;
+}
+/* One stage of the same backward (0: FC head + block4, 1: block3, 2: block2, 3: block1 + stem; call them in this order).
+ * When a stage's kernels are done, the gradients of stabnet_net_grad_bucket(stage) are final for this tower. */
+int stabnet_tower_bwd_stage(const void* netp, const float* params, const float* d_theta, float* grads, void* workspace,
+                            size_t workspace_bytes, int stage, void* stream, void* prof) {
+    const Net* net = static_cast<const Net*>(netp);
+    int rc = tower_bwd_checks(net, params, d_theta, grads, workspace, workspace_bytes, netp, stream);
+    if (rc) return rc;
+    SN_REQUIRE(stage >= 0 && stage < kNumStages, "tower_bwd_stage: stage %d outside [0, %d)", stage, kNumStages);
+    return run_backward_stage(net, params, d_theta, grads, static_cast<float*>(workspace), stage, (hipStream_t)stream,
+                              static_cast<Prof*>(prof));
+}
+int stabnet_net_num_grad_stages(void) { return kNumStages; }
+/* Float range [lo, hi) of the gradient buffer that backward stage `stage` completes (weights and biases in network order;
+ * the BN gamma / beta sections [stabnet_net_bn_grad_range] are touched by every stage and are final after the last one). */
+int stabnet_net_grad_bucket(const void* netp, int stage, long* lo, long* hi) {
+    const Net* net = static_cast<const Net*>(netp);
+    SN_REQUIRE(net && lo && hi && stage >= 0 && stage < kNumStages && net->units.size() == 16, "grad_bucket: bad arguments");
+    int u_hi, u_lo;
+    stage_units(net, stage, u_hi, u_lo);
+    const UnitInfo& first = net->units[u_lo];
+    *lo = (stage == kNumStages - 1) ? 0 : (first.proj ? std::min(first.w_sc, first.w1) : first.w1);
+    if (stage == 0) *hi = (long)net->off_gamma;
+    else {
+        int ph, pl;
+        stage_units(net, stage - 1, ph, pl);
+        const UnitInfo& nx = net->units[pl];
+        *hi = nx.proj ? std::min(nx.w_sc, nx.w1) : nx.w1;
+    }
+    return STABNET_OK;
+}
+int stabnet_net_bn_grad_range(const void* netp, long* lo, long* hi) {
+    const Net* net = static_cast<const Net*>(netp);
+    SN_REQUIRE(net && lo && hi, "bn_grad_range: null pointer");
+    *lo = (long)net->off_gamma; *hi = (long)net->n_trainable;
+    return STABNET_OK;
 }
 
 /* Batch-statistics view of a tower's last forward: folded (scale, shift) [2][G] copied out for inspection/tests. */
@@ -995,19 +1107,26 @@ int stabnet_net_train_bn_offsets(const void* netp, long* scale_off, long* shift_
 /* slim L2 regularisers (s_net_bundle_nobm.py:324-325; resnet.py:35-37): value = sum_seg coef*0.5*sum w^2 added to
  * *loss_out (zero it first; may be NULL); grads[seg] += gscale*coef*w (grads may be NULL).  seg_* are DEVICE arrays. */
 int stabnet_weight_decay(const float* params, float* grads, const long* seg_off, const long* seg_len,
-                         const float* seg_coef, int nseg, float gscale, float* loss_out, void* stream) {
+                         const float* seg_coef, int nseg, float gscale, float* loss_out, float* workspace, void* stream) {
     SN_REQUIRE(params && seg_off && seg_len && seg_coef && nseg > 0 && nseg <= 65535, "weight_decay: bad arguments");
-    return launch_weight_decay(params, grads, seg_off, seg_len, seg_coef, nseg, gscale, loss_out, (hipStream_t)stream);
+    SN_REQUIRE(loss_out == nullptr || workspace != nullptr, "weight_decay: the loss value needs a workspace of 64*nseg floats");
+    return launch_weight_decay(params, grads, seg_off, seg_len, seg_coef, nseg, gscale, loss_out, workspace, (hipStream_t)stream);
 }
 
-/* tf.train.AdamOptimizer.apply_gradients (train_bundle_nobm.py:159-160): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
- * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_t m / (sqrt(v) + eps).  g is scaled by gscale first
- * (1/world for data-parallel averaging); g = grads + grads2 when grads2 is given (one buffer per siamese tower). */
+/* tf.train.AdamOptimizer.apply_gradients (train_bundle_nobm.py:159-160), TF 1.x ApplyAdam op for op in float32:
+ *   alpha = lr * sqrt(1 - beta2_power) / (1 - beta1_power)   (the powers are float32 running products, as TF's
+ *   beta1_power / beta2_power variables are: initialised to beta, multiplied by beta after every step)
+ *   m += (g - m)(1 - b1); v += (g*g - v)(1 - b2); w -= (m * alpha) / (sqrt(v) + eps).   `step` is 1-based.
+ * g is scaled by gscale first (1/world for data-parallel averaging); g = grads + grads2 when grads2 is given. */
 int stabnet_adam_step(float* params, const float* grads, const float* grads2, float* m, float* v, long n, float lr,
                       float beta1, float beta2, float eps, int step, float gscale, void* stream) {
     SN_REQUIRE(params && grads && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
-    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
-    return launch_adam(params, grads, grads2, m, v, n, (float)lr_t, beta1, beta2, eps, gscale, (hipStream_t)stream);
+    // beta^step as TF holds it: a float32 product built one multiplication per step (cached so that consecutive steps cost one)
+    static thread_local struct { float b1, b2, p1, p2; int step; } c = {0.f, 0.f, 0.f, 0.f, 0};
+    if (c.step == 0 || c.b1 != beta1 || c.b2 != beta2 || step < c.step) { c.b1 = beta1; c.b2 = beta2; c.p1 = beta1; c.p2 = beta2; c.step = 1; }
+    for (; c.step < step; ++c.step) { c.p1 = c.p1 * beta1; c.p2 = c.p2 * beta2; }
+    const float alpha = lr * sqrtf(1.0f - c.p2) / (1.0f - c.p1);
+    return launch_adam(params, grads, grads2, m, v, n, alpha, beta1, beta2, eps, gscale, (hipStream_t)stream);
 }
 
 }  // extern "C"

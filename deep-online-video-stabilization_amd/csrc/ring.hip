@@ -95,6 +95,9 @@ __global__ __launch_bounds__(256) void stack_assemble_bordered_kernel(const floa
     const long npix = min((long)256, hwp - i0);
     float* o = out + ((long)s * hwp + i0) * Cp;
     for (long k = threadIdx.x; k < npix * Cp; k += 256) o[k] = tile[k];
+    // slack behind the last image: the stem's last 32-float run reads up to 31 floats past its taps (they meet zero
+    // weights, but 0 * NaN = NaN, and the workspace is not initialised)
+    if (blockIdx.x == 0 && s == (int)gridDim.y - 1 && threadIdx.x < 64) out[(long)gridDim.y * hwp * Cp + threadIdx.x] = 0.f;
 }
 
 // x [N][H][W][C] -> out [N][H+2b][W+2b][C] with a zero border (the non-deploy entry of the same stem).
@@ -112,6 +115,7 @@ __global__ __launch_bounds__(256) void embed_border_kernel(const float* __restri
     float v = 0.f;
     if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = x[(((long)n * H + y) * W + xx) * C + c];
     out[(long)n * total + q] = v;
+    if (q < 64 && n == (int)gridDim.y - 1) out[(long)gridDim.y * total + q] = 0.f;   // slack behind the last image (see above)
 }
 
 // frame = img + black * (-1) (:293); push frame and black into slot `head` (:322-323).

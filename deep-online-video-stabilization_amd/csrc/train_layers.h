@@ -23,12 +23,20 @@ int launch_gap_bwd(const float* dg, int N, int HW, int C, float* da, hipStream_t
 int launch_fc_bwd(const float* x, const float* w, const float* y, const float* dy, int M, int K, int Nout, int relu,
                   float* dW, float* db, float* dx, hipStream_t st);
 int launch_weight_decay(const float* params, float* grads, const long* seg_off, const long* seg_len, const float* seg_coef,
-                        int nseg, float gscale, float* loss_out, hipStream_t st);
+                        int nseg, float gscale, float* loss_out, float* partial, hipStream_t st);
 int launch_adam(float* w, const float* g, const float* g2, float* m, float* v, long n, float lr_t, float b1, float b2,
                 float eps, float gscale, hipStream_t st);
 
-int wgrad_launch(const float* x, const float* dy, float* dw, const float* in_scale, const float* in_shift, int N, int H,
-                 int W, int Cin, int Cout, int KH, int KW, int stride, int pad, hipStream_t st, Prof* prof);
+// wgrad: per-split partial slabs reduced in split order by wgrad_reduce_flush (conv_bwd.hip)
+#define WGRAD_TABLE_MAX 64
+struct WgradReduceEntry { long dw_off, slab_off, elems; int splits; };
+struct WgradReduceTable { WgradReduceEntry e[WGRAD_TABLE_MAX]; long prefix[WGRAD_TABLE_MAX + 1]; int n; };
+int wgrad_splits(int Cout, int K, int M, int* rows_per_split);
+size_t wgrad_slab_floats(int Cout, int K, int M);
+int wgrad_reduce_flush(float* grads, const float* slabs, WgradReduceTable& t, hipStream_t st);
+int wgrad_launch(const float* x, const float* dy, float* dw_base, long dw_off, const float* in_scale, const float* in_shift,
+                 int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* slab_base,
+                 size_t* slab_cursor, WgradReduceTable* table, hipStream_t st, Prof* prof);
 int pack_dgrad_weights(const float* w, float* wt, int Cout, int KH, int KW, int Cin, hipStream_t st);
 // every dgrad weight tensor of a net, re-packed by one launch: layer i = params[w_off ...] OHWI [Cout][K][K][Cin] ->
 // wt[prefix[i] ...] as [Cin][K][K][Cout] with both filter axes flipped

@@ -267,41 +267,52 @@ __global__ __launch_bounds__(256) void fc_bwd_w_kernel(const float* __restrict__
     if (k == 0) db[n] += bacc;
 }
 
-// dx[m][k] = sum_n dyr[m][n] W[n][k]; n range split over blockIdx.y, float atomics into zeroed dx.
-__global__ __launch_bounds__(256) void fc_bwd_x_kernel(const float* __restrict__ w, const float* __restrict__ y,
-                                                       const float* __restrict__ dy, int M, int K, int Nout, int relu,
-                                                       int n_per_block, float* __restrict__ dx) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
-    const int nb = blockIdx.y * n_per_block, ne = min(Nout, nb + n_per_block);
+// dx[m][k] = sum_n dyr[m][n] W[n][k].  Block = 64 k-columns x 16 waves; wave w takes n = w, w+16, ... and the 16 partial
+// sums meet in LDS in wave order: no atomics, reproducible.  M is processed 8 rows at a time.
+__global__ __launch_bounds__(1024) void fc_bwd_x_kernel(const float* __restrict__ w, const float* __restrict__ y,
+                                                        const float* __restrict__ dy, int M, int K, int Nout, int relu,
+                                                        float* __restrict__ dx) {
+    __shared__ float part[16][8][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane;
     for (int m0 = 0; m0 < M; m0 += 8) {
         float acc[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-        for (int n = nb; n < ne; ++n) {
-            const float wv = w[(size_t)n * K + k];
+        if (k < K) {
+            for (int n = wv; n < Nout; n += 16) {
+                const float wvv = w[(size_t)n * K + k];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = m0 + i;
-                if (m < M) {
-                    float d = dy[(size_t)m * Nout + n];
-                    if (relu && !(y[(size_t)m * Nout + n] > 0.f)) d = 0.f;
-                    acc[i] += d * wv;
+                for (int i = 0; i < 8; ++i) {
+                    const int m = m0 + i;
+                    if (m < M) {
+                        float d = dy[(size_t)m * Nout + n];
+                        if (relu && !(y[(size_t)m * Nout + n] > 0.f)) d = 0.f;
+                        acc[i] += d * wvv;
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (m0 + i < M) atomicAdd(&dx[(size_t)(m0 + i) * K + k], acc[i]);
+        for (int i = 0; i < 8; ++i) part[wv][i][lane] = acc[i];
+        __syncthreads();
+        if (wv < 8 && m0 + wv < M && k < K) {                    // wave i finishes row m0 + i
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += part[q][wv][lane];
+            dx[(size_t)(m0 + wv) * K + k] = s;
+        }
+        __syncthreads();
     }
 }
 
-// Weight decay: loss += coef_seg * 0.5 * sum w^2 (value into *loss_out via atomics), grad += gscale * coef_seg * w.
+// Weight decay: loss += coef_seg * 0.5 * sum w^2 (block partials, summed in a fixed order by weight_decay_finalize_kernel),
+// grad += gscale * coef_seg * w.
 // seg table (device): [offset, length] as int64 pairs + coef as float, one block column per segment.
 __global__ __launch_bounds__(256) void weight_decay_kernel(const float* __restrict__ params, float* __restrict__ grads,
                                                            const long* __restrict__ seg_off, const long* __restrict__ seg_len,
                                                            const float* __restrict__ seg_coef, float gscale,
-                                                           float* __restrict__ loss_out) {
+                                                           float* __restrict__ partial) {
     const int sgi = blockIdx.y;
     const long off = seg_off[sgi], len = seg_len[sgi];
     const float coef = seg_coef[sgi];
@@ -311,23 +322,36 @@ __global__ __launch_bounds__(256) void weight_decay_kernel(const float* __restri
         s += w * w;
         if (grads != nullptr) grads[off + i] += gscale * coef * w;
     }
-    if (loss_out != nullptr) {
+    if (partial != nullptr) {
         for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
         __shared__ float red[4];
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(loss_out, 0.5f * coef * ((red[0] + red[1]) + (red[2] + red[3])));
+        if (threadIdx.x == 0) partial[(size_t)sgi * gridDim.x + blockIdx.x] = 0.5f * coef * ((red[0] + red[1]) + (red[2] + red[3]));
     }
 }
+__global__ __launch_bounds__(64) void weight_decay_finalize_kernel(const float* __restrict__ partial, int n, float* __restrict__ loss_out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) s += (double)partial[i];
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) *loss_out += (float)s;
+}
 
-// tf.train.AdamOptimizer step (TF 1.x): lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);
-// m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  w -= lr_t * m / (sqrt(v) + eps).   g is multiplied by gscale first.
+// tf.train.AdamOptimizer step, the ApplyAdam kernel of TF 1.x op for op (one rounding per op, -ffp-contract=off):
+//   m += (g - m) * (1 - b1);  v += (g*g - v) * (1 - b2);  w -= (m * alpha) / (sqrt(v) + eps)
+// alpha = lr * sqrt(1 - b2^t) / (1 - b1^t) is formed on the host.  g is (g + g2) * gscale (g2 optional, gscale = 1/world).
+__device__ __forceinline__ void adam_elem(float& w, float& m, float& v, float g, float alpha, float omb1, float omb2, float eps) {
+    m = m + (g - m) * omb1;
+    v = v + (g * g - v) * omb2;
+    w = w - (m * alpha) / (sqrtf(v) + eps);
+}
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                    const float* __restrict__ g2, float* __restrict__ m,
-                                                   float* __restrict__ v, long n, float lr_t, float b1, float b2,
+                                                   float* __restrict__ v, long n, float alpha, float b1, float b2,
                                                    float eps, float gscale) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
+    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
     if (i + 3 < n) {
         float4 wv = *reinterpret_cast<float4*>(w + i), mv = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
         float4 gv = *reinterpret_cast<const float4*>(g + i);
@@ -335,20 +359,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
             const float4 hv = *reinterpret_cast<const float4*>(g2 + i);
             gv.x += hv.x; gv.y += hv.y; gv.z += hv.z; gv.w += hv.w;
         }
-        gv.x *= gscale; gv.y *= gscale; gv.z *= gscale; gv.w *= gscale;
-        mv.x = b1 * mv.x + (1.f - b1) * gv.x; mv.y = b1 * mv.y + (1.f - b1) * gv.y;
-        mv.z = b1 * mv.z + (1.f - b1) * gv.z; mv.w = b1 * mv.w + (1.f - b1) * gv.w;
-        vv.x = b2 * vv.x + (1.f - b2) * gv.x * gv.x; vv.y = b2 * vv.y + (1.f - b2) * gv.y * gv.y;
-        vv.z = b2 * vv.z + (1.f - b2) * gv.z * gv.z; vv.w = b2 * vv.w + (1.f - b2) * gv.w * gv.w;
-        wv.x -= lr_t * mv.x / (sqrtf(vv.x) + eps); wv.y -= lr_t * mv.y / (sqrtf(vv.y) + eps);
-        wv.z -= lr_t * mv.z / (sqrtf(vv.z) + eps); wv.w -= lr_t * mv.w / (sqrtf(vv.w) + eps);
+        if (gscale != 1.f) { gv.x *= gscale; gv.y *= gscale; gv.z *= gscale; gv.w *= gscale; }
+        adam_elem(wv.x, mv.x, vv.x, gv.x, alpha, omb1, omb2, eps);
+        adam_elem(wv.y, mv.y, vv.y, gv.y, alpha, omb1, omb2, eps);
+        adam_elem(wv.z, mv.z, vv.z, gv.z, alpha, omb1, omb2, eps);
+        adam_elem(wv.w, mv.w, vv.w, gv.w, alpha, omb1, omb2, eps);
         *reinterpret_cast<float4*>(w + i) = wv; *reinterpret_cast<float4*>(m + i) = mv; *reinterpret_cast<float4*>(v + i) = vv;
     } else {
         for (long j = i; j < n; ++j) {
-            const float gg = (g[j] + (g2 != nullptr ? g2[j] : 0.f)) * gscale;
-            m[j] = b1 * m[j] + (1.f - b1) * gg;
-            v[j] = b2 * v[j] + (1.f - b2) * gg * gg;
-            w[j] -= lr_t * m[j] / (sqrtf(v[j]) + eps);
+            float gg = g[j] + (g2 != nullptr ? g2[j] : 0.f);
+            if (gscale != 1.f) gg *= gscale;
+            adam_elem(w[j], m[j], v[j], gg, alpha, omb1, omb2, eps);
         }
     }
 }
@@ -448,27 +469,27 @@ int launch_fc_bwd(const float* x, const float* w, const float* y, const float* d
     fc_bwd_w_kernel<<<dim3(cdiv(K, 256), Nout), 256, 0, st>>>(x, y, dy, M, K, Nout, relu, dW, db);
     SN_LAUNCH_CHECK("fc_bwd_w_kernel");
     if (dx != nullptr) {
-        if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)M * K, st) != hipSuccess) {
-            stabnet_set_error("fc_bwd: memset failed");
-            return STABNET_ERR_LAUNCH;
-        }
-        const int npb = 32;
-        fc_bwd_x_kernel<<<dim3(cdiv(K, 256), cdiv(Nout, npb)), 256, 0, st>>>(w, y, dy, M, K, Nout, relu, npb, dx);
+        fc_bwd_x_kernel<<<cdiv(K, 64), 1024, 0, st>>>(w, y, dy, M, K, Nout, relu, dx);
         SN_LAUNCH_CHECK("fc_bwd_x_kernel");
     }
     return STABNET_OK;
 }
 
 int launch_weight_decay(const float* params, float* grads, const long* seg_off, const long* seg_len, const float* seg_coef,
-                        int nseg, float gscale, float* loss_out, hipStream_t st) {
-    weight_decay_kernel<<<dim3(64, nseg), 256, 0, st>>>(params, grads, seg_off, seg_len, seg_coef, gscale, loss_out);
+                        int nseg, float gscale, float* loss_out, float* partial, hipStream_t st) {
+    weight_decay_kernel<<<dim3(64, nseg), 256, 0, st>>>(params, grads, seg_off, seg_len, seg_coef, gscale,
+                                                        loss_out != nullptr ? partial : nullptr);
     SN_LAUNCH_CHECK("weight_decay_kernel");
+    if (loss_out != nullptr) {
+        weight_decay_finalize_kernel<<<1, 64, 0, st>>>(partial, 64 * nseg, loss_out);
+        SN_LAUNCH_CHECK("weight_decay_finalize_kernel");
+    }
     return STABNET_OK;
 }
 
-int launch_adam(float* w, const float* g, const float* g2, float* m, float* v, long n, float lr_t, float b1, float b2,
+int launch_adam(float* w, const float* g, const float* g2, float* m, float* v, long n, float alpha, float b1, float b2,
                 float eps, float gscale, hipStream_t st) {
-    adam_kernel<<<cdiv((n + 3) / 4, 256), 256, 0, st>>>(w, g, g2, m, v, n, lr_t, b1, b2, eps, gscale);
+    adam_kernel<<<cdiv((n + 3) / 4, 256), 256, 0, st>>>(w, g, g2, m, v, n, alpha, b1, b2, eps, gscale);
     SN_LAUNCH_CHECK("adam_kernel");
     return STABNET_OK;
 }

@@ -28,7 +28,7 @@ __device__ __forceinline__ int cvt_i32_x86(float f) {
 // LU with partial pivoting + two column-oriented triangular solves == Eigen PartialPivLU::inverse() for n=8.
 __global__ __launch_bounds__(256) void mesh_homography_kernel(const float* __restrict__ in, int in_is_theta, int N,
                                                               int gh, int gw, float lim, float* __restrict__ pts2_out,
-                                                              float* __restrict__ Hs_out) {
+                                                              float* __restrict__ Hs_out, float* __restrict__ pts1_out) {
     const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     const int cells = gh * gw;
@@ -63,6 +63,8 @@ __global__ __launch_bounds__(256) void mesh_homography_kernel(const float* __res
             pts2_out[((size_t)n * nv + v) * 2 + 1] = py;
         }
     }
+    if (pts1_out != nullptr && lane < 8)                 // [x_TL,x_TR,x_BL,x_BR,y_TL,y_TR,y_BL,y_BR], s_net_bundle_nobm.py:65-66
+        pts1_out[((size_t)n * cells + cell) * 8 + lane] = (lane < 4) ? tu[lane & 3] : tv[lane & 3];
 
     const int r = lane >> 3, c = lane & 7;
     const int q = r & 3;
@@ -165,70 +167,103 @@ __device__ __forceinline__ float sample4(const float* __restrict__ img, const Sa
 
 // Tile = 4 rows x 256 columns per 256-thread block; thread = 4 consecutive pixels of one row.
 // grid = (ceil(W/256), ceil(H/4), N).
-template <int VEC>
+// PUSH = 1 (online loop, C == 1, W % 4 == 0): the feedback of deploy_bundle.py:291-295,319-323 rides on the same pass --
+//   frame = img + black * (-1) -> frames_ring[head], black -> masks_ring[head], frame -> frame_out, all_black += round(black)
+//   -- and the LAST block to finish (ticket counter) advances the device-side ring head, so the frame needs no push /
+//   advance launches.  Every block reads `head` before it takes its ticket, so the advance cannot overtake a reader.
+template <int VEC, int PUSH>
 __global__ __launch_bounds__(256) void warp_sample_kernel(const float* __restrict__ Hs, const float* __restrict__ src,
                                                           int H, int W, int C, int gh, int gw,
                                                           float* __restrict__ out, float* __restrict__ black,
-                                                          float* __restrict__ x_map, float* __restrict__ y_map) {
+                                                          float* __restrict__ x_map, float* __restrict__ y_map,
+                                                          const WarpPush push) {
     __shared__ float sH[SN_MAX_CELLS * 9];
     const int n = blockIdx.z;
     const int cells = gh * gw;
     for (int i = threadIdx.x; i < cells * 9; i += 256) sH[i] = Hs[(size_t)n * cells * 9 + i];
+    int head = 0;
+    if (PUSH) head = *push.head;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int y = blockIdx.y * 4 + wv;
     const int xb = blockIdx.x * 256 + lane * 4;
-    if (y >= H || xb >= W) return;
+    if (y < H && xb < W) {
+        const int chh = H / gh, cww = W / gw;               // floor, :227-228
+        const int ci = min(y / chh, gh - 1);
+        const float stepx = (W > 1) ? 2.0f / (float)(W - 1) : 0.0f;       // LinSpace: start + step*i
+        const float stepy = (H > 1) ? 2.0f / (float)(H - 1) : 0.0f;
+        const float gy = -1.0f + stepy * (float)y;
+        const float* img = src + (size_t)n * H * W * C;
+        const size_t rowoff = ((size_t)n * H + y) * W;
 
-    const int chh = H / gh, cww = W / gw;               // floor, :227-228
-    const int ci = min(y / chh, gh - 1);
-    const float stepx = (W > 1) ? 2.0f / (float)(W - 1) : 0.0f;       // LinSpace: start + step*i
-    const float stepy = (H > 1) ? 2.0f / (float)(H - 1) : 0.0f;
-    const float gy = -1.0f + stepy * (float)y;
-    const float* img = src + (size_t)n * H * W * C;
-    const size_t rowoff = ((size_t)n * H + y) * W;
-
-    float xm[4], ym[4], bl[4], o[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int xx = min(xb + e, W - 1);
-        const int cj = min(xx / cww, gw - 1);
-        const float* h = sH + (ci * gw + cj) * 9;
-        const float gx = -1.0f + stepx * (float)xx;
-        const float tx = (h[0] * gx + h[1] * gy) + h[2];
-        const float ty = (h[3] * gx + h[4] * gy) + h[5];
-        float tz = (h[6] * gx + h[7] * gy) + h[8];
-        const float sgn = ((tz >= 0.0f) ? 1.0f : 0.0f) * 2.0f - 1.0f;  // :257
-        tz = tz + sgn * 1e-8f;                                          // :258
-        xm[e] = tx / tz;
-        ym[e] = ty / tz;
-        bl[e] = ((-1.0f > xm[e]) || (xm[e] > 1.0f) || (-1.0f > ym[e]) || (ym[e] > 1.0f)) ? 1.0f : 0.0f;
-    }
-    if (C == 1) {
+        float xm[4], ym[4], bl[4], o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const SampleTaps t = make_taps(xm[e], ym[e], H, W);
-            o[e] = sample4(img, t, 1, 0);
+            const int xx = min(xb + e, W - 1);
+            const int cj = min(xx / cww, gw - 1);
+            const float* h = sH + (ci * gw + cj) * 9;
+            const float gx = -1.0f + stepx * (float)xx;
+            const float tx = (h[0] * gx + h[1] * gy) + h[2];
+            const float ty = (h[3] * gx + h[4] * gy) + h[5];
+            float tz = (h[6] * gx + h[7] * gy) + h[8];
+            const float sgn = ((tz >= 0.0f) ? 1.0f : 0.0f) * 2.0f - 1.0f;  // :257
+            tz = tz + sgn * 1e-8f;                                          // :258
+            xm[e] = tx / tz;
+            ym[e] = ty / tz;
+            bl[e] = ((-1.0f > xm[e]) || (xm[e] > 1.0f) || (-1.0f > ym[e]) || (ym[e] > 1.0f)) ? 1.0f : 0.0f;
+        }
+        if (C == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const SampleTaps t = make_taps(xm[e], ym[e], H, W);
+                o[e] = sample4(img, t, 1, 0);
+            }
+        }
+        if (VEC == 4 && xb + 3 < W) {
+            *reinterpret_cast<float4*>(x_map + rowoff + xb) = make_float4(xm[0], xm[1], xm[2], xm[3]);
+            *reinterpret_cast<float4*>(y_map + rowoff + xb) = make_float4(ym[0], ym[1], ym[2], ym[3]);
+            *reinterpret_cast<float4*>(black + rowoff + xb) = make_float4(bl[0], bl[1], bl[2], bl[3]);
+            if (C == 1) *reinterpret_cast<float4*>(out + rowoff + xb) = make_float4(o[0], o[1], o[2], o[3]);
+            if (PUSH) {
+                const size_t hw = (size_t)H * W, pix = (size_t)y * W + xb;
+                const float4 f = make_float4(o[0] + bl[0] * -1.0f, o[1] + bl[1] * -1.0f, o[2] + bl[2] * -1.0f,
+                                             o[3] + bl[3] * -1.0f);                                    // :293
+                const size_t slot = ((size_t)n * push.depth + head) * hw + pix;
+                *reinterpret_cast<float4*>(push.frames + slot) = f;                                    // :322
+                *reinterpret_cast<float4*>(push.masks + slot) = make_float4(bl[0], bl[1], bl[2], bl[3]);   // :323
+                *reinterpret_cast<float4*>(push.frame_out + (size_t)n * hw + pix) = f;
+                if (push.all_black != nullptr) {                                                       // :291
+                    int4* ab = reinterpret_cast<int4*>(push.all_black + (size_t)n * hw + pix);
+                    int4 v = *ab;
+                    v.x += (int)bl[0]; v.y += (int)bl[1]; v.z += (int)bl[2]; v.w += (int)bl[3];
+                    *ab = v;
+                }
+            }
+        } else {
+            for (int e = 0; e < 4 && xb + e < W; ++e) {
+                x_map[rowoff + xb + e] = xm[e];
+                y_map[rowoff + xb + e] = ym[e];
+                black[rowoff + xb + e] = bl[e];
+                if (C == 1) out[rowoff + xb + e] = o[e];
+            }
+        }
+        if (C != 1) {
+            for (int e = 0; e < 4 && xb + e < W; ++e) {
+                const SampleTaps t = make_taps(xm[e], ym[e], H, W);
+                for (int ch = 0; ch < C; ++ch) out[(rowoff + xb + e) * C + ch] = sample4(img, t, C, ch);
+            }
         }
     }
-    if (VEC == 4 && xb + 3 < W) {
-        *reinterpret_cast<float4*>(x_map + rowoff + xb) = make_float4(xm[0], xm[1], xm[2], xm[3]);
-        *reinterpret_cast<float4*>(y_map + rowoff + xb) = make_float4(ym[0], ym[1], ym[2], ym[3]);
-        *reinterpret_cast<float4*>(black + rowoff + xb) = make_float4(bl[0], bl[1], bl[2], bl[3]);
-        if (C == 1) *reinterpret_cast<float4*>(out + rowoff + xb) = make_float4(o[0], o[1], o[2], o[3]);
-    } else {
-        for (int e = 0; e < 4 && xb + e < W; ++e) {
-            x_map[rowoff + xb + e] = xm[e];
-            y_map[rowoff + xb + e] = ym[e];
-            black[rowoff + xb + e] = bl[e];
-            if (C == 1) out[rowoff + xb + e] = o[e];
-        }
-    }
-    if (C != 1) {
-        for (int e = 0; e < 4 && xb + e < W; ++e) {
-            const SampleTaps t = make_taps(xm[e], ym[e], H, W);
-            for (int ch = 0; ch < C; ++ch) out[(rowoff + xb + e) * C + ch] = sample4(img, t, C, ch);
+    if (PUSH) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+            const unsigned old = atomicAdd(reinterpret_cast<unsigned*>(push.ticket), 1u);
+            if (old == total - 1) {                       // every block has read `head` (before its own ticket)
+                *push.ticket = 0;
+                *push.head_rw = (head + 1) % push.depth;
+            }
         }
     }
 }
@@ -273,9 +308,9 @@ int check_warp_args(int N, int H, int W, int C, int gh, int gw) {
 }
 
 int launch_mesh(const float* in, int is_theta, int N, int gh, int gw, float lim, float* pts2, float* Hs,
-                       hipStream_t st) {
+                       hipStream_t st, float* pts1) {
     const long waves = (long)N * gh * gw;
-    mesh_homography_kernel<<<cdiv(waves * 64, 256), 256, 0, st>>>(in, is_theta, N, gh, gw, lim, pts2, Hs);
+    mesh_homography_kernel<<<cdiv(waves * 64, 256), 256, 0, st>>>(in, is_theta, N, gh, gw, lim, pts2, Hs, pts1);
     SN_LAUNCH_CHECK("mesh_homography_kernel");
     return STABNET_OK;
 }
@@ -283,22 +318,34 @@ int launch_mesh(const float* in, int is_theta, int N, int gh, int gw, float lim,
 int launch_sample(const float* Hs, const float* src, int N, int H, int W, int C, int gh, int gw, float* out,
                          float* black, float* x_map, float* y_map, hipStream_t st) {
     dim3 grid(cdiv(W, 256), cdiv(H, 4), N);
+    const WarpPush none{};
     if ((W & 3) == 0)
-        warp_sample_kernel<4><<<grid, 256, 0, st>>>(Hs, src, H, W, C, gh, gw, out, black, x_map, y_map);
+        warp_sample_kernel<4, 0><<<grid, 256, 0, st>>>(Hs, src, H, W, C, gh, gw, out, black, x_map, y_map, none);
     else
-        warp_sample_kernel<1><<<grid, 256, 0, st>>>(Hs, src, H, W, C, gh, gw, out, black, x_map, y_map);
+        warp_sample_kernel<1, 0><<<grid, 256, 0, st>>>(Hs, src, H, W, C, gh, gw, out, black, x_map, y_map, none);
+    SN_LAUNCH_CHECK("warp_sample_kernel");
+    return STABNET_OK;
+}
+
+// The online loop's last pass: sample + feedback push + ring-head advance in one launch (C = 1, W % 4 == 0).
+int launch_sample_push(const float* Hs, const float* src, int N, int H, int W, int gh, int gw, float* out, float* black,
+                       float* x_map, float* y_map, const WarpPush& push, hipStream_t st) {
+    SN_REQUIRE((W & 3) == 0 && push.frames && push.masks && push.frame_out && push.head && push.head_rw && push.ticket &&
+                   push.depth > 0, "sample_push: bad arguments");
+    dim3 grid(cdiv(W, 256), cdiv(H, 4), N);
+    warp_sample_kernel<4, 1><<<grid, 256, 0, st>>>(Hs, src, H, W, 1, gh, gw, out, black, x_map, y_map, push);
     SN_LAUNCH_CHECK("warp_sample_kernel");
     return STABNET_OK;
 }
 
 extern "C" {
 
-int stabnet_get_4_pts(const float* theta, int N, int grid_h, int grid_w, float do_crop_rate, float* pts2, float* Hs,
-                      void* stream) {
+int stabnet_get_4_pts(const float* theta, int N, int grid_h, int grid_w, float do_crop_rate, float* pts1, float* pts2,
+                      float* Hs, void* stream) {
     SN_REQUIRE(theta && pts2 && Hs, "get_4_pts: null pointer");
     SN_REQUIRE(N > 0 && grid_h > 0 && grid_w > 0 && grid_h * grid_w <= SN_MAX_CELLS, "get_4_pts: bad shape");
     SN_REQUIRE(do_crop_rate > 0.f, "get_4_pts: do_crop_rate must be > 0");
-    return launch_mesh(theta, 1, N, grid_h, grid_w, 1.0f / do_crop_rate, pts2, Hs, (hipStream_t)stream);
+    return launch_mesh(theta, 1, N, grid_h, grid_w, 1.0f / do_crop_rate, pts2, Hs, (hipStream_t)stream, pts1);
 }
 
 int stabnet_transformer_fwd(const float* pts2, const float* U, int N, int H, int W, int C, int grid_h, int grid_w,

@@ -4,12 +4,21 @@
 //   interpolate(out2, flow)         spatial_transformer.py:200-281    -> d im              (scatter-add of the 4 taps)
 //   feature / img / temporal / mesh losses   s_net_bundle_nobm.py:139-210,335-352, train_bundle_nobm.py:110-125
 // floor / casts / comparisons carry no gradient: corners, black_pix, the z sign and warp_pts indices are constants.
-// All kernels are HBM-bound or tiny; reductions across blocks use float atomics on small zero-initialised buffers.
+// All kernels are HBM-bound or tiny.  Every cross-thread reduction is ORDER-INDEPENDENT, so a training step is
+// reproducible bit for bit: sums that many blocks contribute to are accumulated as 64-bit FIXED-POINT integers
+// (integer addition is associative; scale 2^40: resolution 9.1e-13, range +-8.3e6 -- gradients of this objective are
+// 1e-9 .. 1e2), or as block partials reduced in a fixed order by a second small kernel.
 #include "common.h"
 #include <algorithm>
 #include <climits>
 
 #define SN_MAX_CELLS 64
+#define SN_FIX_SCALE 1099511627776.0            // 2^40
+#define SN_FIX_INV (1.0 / 1099511627776.0)
+
+typedef unsigned long long sn_u64;
+__device__ __forceinline__ sn_u64 to_fix(double v) { return (sn_u64)(long long)__double2ll_rn(v * SN_FIX_SCALE); }
+__device__ __forceinline__ double from_fix(sn_u64 v) { return (double)(long long)v * SN_FIX_INV; }
 
 __device__ __forceinline__ float wshfl_b(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int cvt_i32_x86_b(float f) {
@@ -25,14 +34,15 @@ __global__ __launch_bounds__(256) void warp_bwd_pixels_kernel(const float* __res
                                                               const float* __restrict__ d_out,
                                                               const float* __restrict__ d_xmap,
                                                               const float* __restrict__ d_ymap, int H, int W, int C,
-                                                              int gh, int gw, double* __restrict__ dHs) {
+                                                              int gh, int gw, sn_u64* __restrict__ dHs, const float* __restrict__ dmap_scale) {
     __shared__ float sH[SN_MAX_CELLS * 9];
-    __shared__ double sAcc[SN_MAX_CELLS * 8];      // float64: the 8x8 adjoint solve amplifies rounding of these sums
+    __shared__ sn_u64 sAcc[SN_MAX_CELLS * 8];      // fixed point (the 8x8 adjoint solve amplifies rounding of these sums: no float32)
     const int n = blockIdx.z;
     const int cells = gh * gw;
     for (int i = threadIdx.x; i < cells * 9; i += 256) sH[i] = Hs[(size_t)n * cells * 9 + i];
-    for (int i = threadIdx.x; i < cells * 8; i += 256) sAcc[i] = 0.0;
+    for (int i = threadIdx.x; i < cells * 8; i += 256) sAcc[i] = 0ull;
     __syncthreads();
+    const float mscale = (dmap_scale != nullptr) ? dmap_scale[n] : 1.0f;   // d_xmap / d_ymap hold counts: gradient = count * scale[n]
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int y = blockIdx.y * 4 + wv;
@@ -78,8 +88,8 @@ __global__ __launch_bounds__(256) void warp_bwd_pixels_kernel(const float* __res
             }
         }
         float dxm = dxp * (float)W / 2.0f, dym = dyp * (float)H / 2.0f;
-        if (d_xmap != nullptr) dxm += d_xmap[rowoff + xx];
-        if (d_ymap != nullptr) dym += d_ymap[rowoff + xx];
+        if (d_xmap != nullptr) dxm += d_xmap[rowoff + xx] * mscale;
+        if (d_ymap != nullptr) dym += d_ymap[rowoff + xx] * mscale;
         const float dtx = dxm / tz, dty = dym / tz, dtz = -(dxm * xm + dym * ym) / tz;
         const float c[8] = {dtx * gx, dtx * gy, dtx, dty * gx, dty * gy, dty, dtz * gx, dtz * gy};
         if (my_cell == -1 || my_cell == cell) {
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(256) void warp_bwd_pixels_kernel(const float* __res
             for (int k = 0; k < 8; ++k) acc[k] += c[k];
         } else {                                           // 4-pixel group straddles a cell seam (rare)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) atomicAdd(&sAcc[cell * 8 + k], (double)c[k]);
+            for (int k = 0; k < 8; ++k) atomicAdd(&sAcc[cell * 8 + k], to_fix((double)c[k]));
         }
     }
     // wave reduction when the whole wave sits in one cell (the common case), LDS atomics otherwise
@@ -100,32 +110,35 @@ __global__ __launch_bounds__(256) void warp_bwd_pixels_kernel(const float* __res
         for (int k = 0; k < 8; ++k) {
             double v = (double)acc[k];
             for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0) atomicAdd(&sAcc[first * 8 + k], v);
+            if (lane == 0) atomicAdd(&sAcc[first * 8 + k], to_fix(v));       // (the butterfly order is fixed)
         }
     } else if (my_cell >= 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(&sAcc[my_cell * 8 + k], (double)acc[k]);
+        for (int k = 0; k < 8; ++k) atomicAdd(&sAcc[my_cell * 8 + k], to_fix((double)acc[k]));
     }
     __syncthreads();
     for (int i = threadIdx.x; i < cells * 8; i += 256) {
-        const double v = sAcc[i];
-        if (v != 0.0) atomicAdd(&dHs[(size_t)n * cells * 8 + i], v);
+        const sn_u64 v = sAcc[i];
+        if (v != 0ull) atomicAdd(&dHs[(size_t)n * cells * 8 + i], v);
     }
 }
 
-// Stage B: one wave per (n, cell): dH[0..7] -> d(target vertices) through h = inv(A + 1e-4 I) b:
+// Stage B: one block per sample, one wave per cell (waves loop when there are more than 16 cells):
+// dH[0..7] -> d(target vertices) through h = inv(A + 1e-4 I) b:
 //   lambda = inv(A)^T dH ;  dL/db = lambda ;  dL/dA = -lambda h^T ; b = [u,v], A[q][6..7] = -(x,y)_q u_q, A[4+q][6..7] = -(x,y)_q v_q.
-// Accumulates into d_pts2 [N, gh+1, gw+1, 2] (zero-initialised by the caller) with atomics.
+// The 8 corner contributions of every cell go to LDS; each vertex then sums its (up to four) cells in the fixed order
+// TL, TR, BL, BR of the cells around it and writes d_pts2 [N, gh+1, gw+1, 2] once: no atomics, no pre-zeroing.
 __device__ __forceinline__ double wshfl_d(double v, int src) { return __shfl(v, src, 64); }
 
-__global__ __launch_bounds__(256) void warp_bwd_mesh_kernel(const float* __restrict__ pts2, const float* __restrict__ Hs,
-                                                            const double* __restrict__ dHs, int N, int gh, int gw,
-                                                            float* __restrict__ d_pts2) {
-    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+__global__ __launch_bounds__(1024) void warp_bwd_mesh_kernel(const float* __restrict__ pts2, const float* __restrict__ Hs,
+                                                             const sn_u64* __restrict__ dHs, int N, int gh, int gw,
+                                                             float* __restrict__ d_pts2) {
+    __shared__ float sC[SN_MAX_CELLS * 8];               // [cell][u_TL,u_TR,u_BL,u_BR,v_TL,v_TR,v_BL,v_BR]
+    const int n = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int cells = gh * gw;
-    if (wave >= N * cells) return;
-    const int n = wave / cells, cell = wave % cells;
+    const int nwaves = blockDim.x >> 6;
+  for (int cell = threadIdx.x >> 6; cell < cells; cell += nwaves) {
     const int ci = cell / gw, cj = cell % gw;
     const double hh = 2.0 / gh, ww = 2.0 / gw;
     const int nv = (gh + 1) * (gw + 1);
@@ -190,30 +203,48 @@ __global__ __launch_bounds__(256) void warp_bwd_mesh_kernel(const float* __restr
         if (r < i) x = x - b * u;
     }
     // lambda_j = sum_k X[k][j] * g[k]   (X = inv(A), lane (k, j) holds X[k][j])
-    const double* g = dHs + ((size_t)n * cells + cell) * 8;
+    const sn_u64* g = dHs + ((size_t)n * cells + cell) * 8;
     double lam = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) lam += wshfl_d(x, k * 8 + c) * g[k];     // valid in every lane with column c
+    for (int k = 0; k < 8; ++k) lam += wshfl_d(x, k * 8 + c) * from_fix(g[k]);     // valid in every lane with column c
     const float* h = Hs + ((size_t)n * cells + cell) * 9;
     const double h6 = (double)h[6], h7 = (double)h[7];
     if (r == 0) {                                        // lanes 0..7: c = index j of lambda
         const int qq = c & 3;
         const double dv = lam + lam * (h6 * sx[qq] + h7 * sy[qq]);         // d/du_q (c<4) or d/dv_q (c>=4)
-        atomicAdd(&d_pts2[((size_t)n * nv + vid[qq]) * 2 + (c < 4 ? 0 : 1)], (float)dv);
+        sC[cell * 8 + c] = (float)dv;
+    }
+  }
+    __syncthreads();
+    const int nvv = (gh + 1) * (gw + 1);
+    for (int t = threadIdx.x; t < nvv * 2; t += blockDim.x) {
+        const int v = t >> 1, d = t & 1;
+        const int vi = v / (gw + 1), vj = v % (gw + 1);
+        float acc = 0.f;
+        // cells around the vertex in the order TL, TR, BL, BR; in cell (ci, cj) the vertex is corner q = (vi-ci)*2 + (vj-cj)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ci = vi - 1 + (k >> 1), cj = vj - 1 + (k & 1);
+            if (ci < 0 || cj < 0 || ci >= gh || cj >= gw) continue;
+            const int q = (vi - ci) * 2 + (vj - cj);
+            acc += sC[(ci * gw + cj) * 8 + d * 4 + q];
+        }
+        d_pts2[((size_t)n * nvv + v) * 2 + d] = acc;
     }
 }
 
-// interpolate() backward wrt the image: d_im[tap] += w_tap * d_out  (d_im zero-initialised by the caller).
+// interpolate() backward wrt the image: acc[tap] += w_tap * d_out as 64-bit fixed point (a scatter has no fixed order:
+// integer adds make the sum order-independent), then d_im (+)= acc in a second pass.
 __global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ ys,
                                                          const float* __restrict__ d_out, int H, int W, int C,
-                                                         float* __restrict__ d_im) {
+                                                         sn_u64* __restrict__ acc_fix) {
     const int n = blockIdx.z;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int y = blockIdx.y * 4 + wv;
     const int xb = blockIdx.x * 256 + lane * 4;
     if (y >= H) return;
     const size_t rowoff = ((size_t)n * H + y) * W;
-    float* dimg = d_im + (size_t)n * H * W * C;
+    sn_u64* dimg = acc_fix + (size_t)n * H * W * C;
     for (int e = 0; e < 4 && xb + e < W; ++e) {
         const float xm = xs[rowoff + xb + e], ym = ys[rowoff + xb + e];
         const float xp = (xm + 1.0f) * (float)W / 2.0f, yp = (ym + 1.0f) * (float)H / 2.0f;
@@ -227,21 +258,29 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict
         for (int ch = 0; ch < C; ++ch) {
             const float g = d_out[(rowoff + xb + e) * C + ch];
             if (g == 0.f) continue;
-            atomicAdd(&dimg[((size_t)y0 * W + x0) * C + ch], wa * g);
-            atomicAdd(&dimg[((size_t)y1 * W + x0) * C + ch], wb * g);
-            atomicAdd(&dimg[((size_t)y0 * W + x1) * C + ch], wc * g);
-            atomicAdd(&dimg[((size_t)y1 * W + x1) * C + ch], wd * g);
+            atomicAdd(&dimg[((size_t)y0 * W + x0) * C + ch], to_fix((double)(wa * g)));
+            atomicAdd(&dimg[((size_t)y1 * W + x0) * C + ch], to_fix((double)(wb * g)));
+            atomicAdd(&dimg[((size_t)y0 * W + x1) * C + ch], to_fix((double)(wc * g)));
+            atomicAdd(&dimg[((size_t)y1 * W + x1) * C + ch], to_fix((double)(wd * g)));
         }
     }
+}
+__global__ __launch_bounds__(256) void fix_to_float_kernel(const sn_u64* __restrict__ acc_fix, long n, float* __restrict__ out,
+                                                           int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = (float)from_fix(acc_fix[i]);
+    out[i] = accumulate ? out[i] + v : v;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Per-sample sums for the masked-MSE losses.  mode 0 (img loss): a = out, b = y, m = 1 - black.
-// mode 1 (temporal): a = out1, b = o2w, m = (1 - black1) * nb2w.   sums[n] = { sum((a-b)m)^2, sum m } via atomics.
+// mode 1 (temporal): a = out1, b = o2w, m = (1 - black1) * nb2w.   sums[n] = { sum((a-b)m)^2, sum m }: block partials
+// (fixed in-block tree), then one wave per sample adds the partials in block order (float64) -- reproducible.
 __global__ __launch_bounds__(256) void masked_mse_sums_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                               const float* __restrict__ black,
                                                               const float* __restrict__ m2, long hw,
-                                                              float* __restrict__ sums) {
+                                                              float* __restrict__ partial) {
     const int n = blockIdx.y;
     float s0 = 0.f, s1 = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
@@ -257,9 +296,21 @@ __global__ __launch_bounds__(256) void masked_mse_sums_kernel(const float* __res
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[n * 2 + 0], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
-        atomicAdd(&sums[n * 2 + 1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+        float* p = partial + ((size_t)n * gridDim.x + blockIdx.x) * 2;
+        p[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        p[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
+}
+__global__ __launch_bounds__(64) void masked_mse_finalize_kernel(const float* __restrict__ partial, int nblocks,
+                                                                 float* __restrict__ sums) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = lane; k < nblocks; k += 64) {                 // lane-strided, then a fixed butterfly
+        s0 += (double)partial[((size_t)n * nblocks + k) * 2];
+        s1 += (double)partial[((size_t)n * nblocks + k) * 2 + 1];
+    }
+    for (int off = 32; off >= 1; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+    if (lane == 0) { sums[n * 2] = (float)s0; sums[n * 2 + 1] = (float)s1; }
 }
 
 // d/d a of  coef * sum_n [ sum((a-b)m)^2 / (sum m + 1e-8) ]:  g = coef * 2 (a-b) m^2 / den_n;  ga (+)= g, gb = -g.
@@ -282,13 +333,15 @@ __global__ __launch_bounds__(256) void masked_mse_grad_kernel(const float* __res
 }
 
 // Feature loss (s_net_bundle_nobm.py:215-230,335-343): one block per sample.
-// value[n] = sum_i mask_i (|xm - ux| + |ym - uy|) / max(sum mask, 1);  d maps at the rounded pixel (atomics; zeroed by caller).
+// value[n] = sum_i mask_i (|xm - ux| + |ym - uy|) / max(sum mask, 1).  Gradient wrt the maps at the rounded pixel: the maps
+// d_xmap / d_ymap receive SIGNED COUNTS (+-mask_i; sums of small integers are exact in float32 whatever the order of the
+// atomics) and dscale[n] = gcoef / max(sum mask, 1) is the factor the consumer multiplies them with (stabnet_transformer_bwd).
 __global__ __launch_bounds__(256) void feature_loss_kernel(const float* __restrict__ matches, const float* __restrict__ mask,
                                                            const float* __restrict__ x_map,
                                                            const float* __restrict__ y_map, int H, int W, int Mx,
                                                            float gcoef, float* __restrict__ value,
                                                            float* __restrict__ d_xmap, float* __restrict__ d_ymap,
-                                                           float* __restrict__ warped) {
+                                                           float* __restrict__ warped, float* __restrict__ dscale) {
     const int n = blockIdx.x;
     __shared__ float red[4];
     __shared__ float s_cnt;
@@ -315,16 +368,18 @@ __global__ __launch_bounds__(256) void feature_loss_kernel(const float* __restri
         const float mk = mask[(size_t)n * Mx + i];
         s += (fabsf(ex) + fabsf(ey)) * mk;
         if (d_xmap != nullptr && mk != 0.f) {
-            const float g = gcoef * mk / cnt;
-            if (ex != 0.f) atomicAdd(&d_xmap[o], ex > 0.f ? g : -g);
-            if (ey != 0.f) atomicAdd(&d_ymap[o], ey > 0.f ? g : -g);
+            if (ex != 0.f) atomicAdd(&d_xmap[o], ex > 0.f ? mk : -mk);
+            if (ey != 0.f) atomicAdd(&d_ymap[o], ey > 0.f ? mk : -mk);
         }
     }
     __syncthreads();
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) value[n] = ((red[0] + red[1]) + (red[2] + red[3])) / cnt;
+    if (threadIdx.x == 0) {
+        value[n] = ((red[0] + red[1]) + (red[2] + red[3])) / cnt;
+        if (dscale != nullptr) dscale[n] = gcoef / cnt;
+    }
 }
 
 // Mesh losses and the final assembly of d theta (one thread per sample; N is small).
@@ -420,7 +475,7 @@ __global__ __launch_bounds__(64) void mesh_losses_kernel(const float* __restrict
                 float g = dp[2 * v + d] + (d_pts2_warp ? d_pts2_warp[((size_t)n * nv + v) * 2 + d] : 0.f);
                 g = pass ? g : 0.f;
                 g += w_id * id_mul * ((th > 0.f) ? 1.f : ((th < 0.f) ? -1.f : 0.f)) / (float)(N * nt);
-                d_theta[(size_t)n * nt + 2 * v + d] = g;
+                if (d_theta != nullptr) d_theta[(size_t)n * nt + 2 * v + d] = g;
             }
     }
     red[0][threadIdx.x] = l_id; red[1][threadIdx.x] = l_black; red[2][threadIdx.x] = l_dist; red[3][threadIdx.x] = l_cons;
@@ -437,43 +492,49 @@ __global__ __launch_bounds__(64) void mesh_losses_kernel(const float* __restrict
 extern "C" {
 
 /* transformer backward (spatial_transformer3.py:218-301 under TF autodiff): d_pts2 [N,gh+1,gw+1,2] (pre-clip vertex
- * gradient).  d_out [N,H,W,C], d_xmap, d_ymap [N,H,W] may each be NULL.  workspace: N*gh*gw*8 DOUBLES (dHs), 8-B aligned. */
+ * gradient).  d_out [N,H,W,C], d_xmap, d_ymap [N,H,W] may each be NULL; dmap_scale [N] (optional) multiplies d_xmap / d_ymap
+ * per sample (the feature loss hands over signed counts + a scale).  workspace: N*gh*gw*8 8-byte words, 8-B aligned. */
 int stabnet_transformer_bwd(const float* pts2, const float* Hs, const float* U, const float* x_map, const float* y_map,
-                            const float* d_out, const float* d_xmap, const float* d_ymap, int N, int H, int W, int C,
-                            int grid_h, int grid_w, float* d_pts2, void* workspace, void* stream) {
+                            const float* d_out, const float* d_xmap, const float* d_ymap, const float* dmap_scale, int N,
+                            int H, int W, int C, int grid_h, int grid_w, float* d_pts2, void* workspace, void* stream) {
     SN_REQUIRE(pts2 && Hs && U && x_map && y_map && d_pts2 && workspace, "transformer_bwd: null pointer");
     SN_REQUIRE(N > 0 && N <= 65535 && H >= grid_h && W >= grid_w && C > 0 && grid_h * grid_w <= SN_MAX_CELLS,
                "transformer_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    const int cells = grid_h * grid_w, nv = (grid_h + 1) * (grid_w + 1);
+    const int cells = grid_h * grid_w;
     SN_REQUIRE(((uintptr_t)workspace & 7) == 0, "transformer_bwd: workspace must be 8-byte aligned");
-    double* dHs = static_cast<double*>(workspace);
-    if (hipMemsetAsync(workspace, 0, sizeof(double) * N * cells * 8, st) != hipSuccess ||
-        hipMemsetAsync(d_pts2, 0, sizeof(float) * N * nv * 2, st) != hipSuccess) {
+    sn_u64* dHs = static_cast<sn_u64*>(workspace);
+    if (hipMemsetAsync(workspace, 0, sizeof(sn_u64) * N * cells * 8, st) != hipSuccess) {
         stabnet_set_error("transformer_bwd: memset failed");
         return STABNET_ERR_LAUNCH;
     }
     dim3 grid(cdiv(W, 256), cdiv(H, 4), N);
-    warp_bwd_pixels_kernel<<<grid, 256, 0, st>>>(Hs, U, x_map, y_map, d_out, d_xmap, d_ymap, H, W, C, grid_h, grid_w, dHs);
+    warp_bwd_pixels_kernel<<<grid, 256, 0, st>>>(Hs, U, x_map, y_map, d_out, d_xmap, d_ymap, H, W, C, grid_h, grid_w, dHs,
+                                                 dmap_scale);
     SN_LAUNCH_CHECK("warp_bwd_pixels_kernel");
-    warp_bwd_mesh_kernel<<<cdiv((long)N * cells * 64, 256), 256, 0, st>>>(pts2, Hs, dHs, N, grid_h, grid_w, d_pts2);
+    warp_bwd_mesh_kernel<<<N, std::min(1024, 64 * cells), 0, st>>>(pts2, Hs, dHs, N, grid_h, grid_w, d_pts2);
     SN_LAUNCH_CHECK("warp_bwd_mesh_kernel");
     return STABNET_OK;
 }
 
-/* interpolate(im, x, y) backward wrt im (train_bundle_nobm.py:117: the gradient that reaches tower 2's output). */
+/* interpolate(im, x, y) backward wrt im (train_bundle_nobm.py:117: the gradient that reaches tower 2's output).
+ * workspace: N*H*W*C 8-byte words (fixed-point accumulators), 8-B aligned. */
 int stabnet_interp_bwd(const float* x, const float* y, const float* d_out, int N, int H, int W, int C, float* d_im,
-                       int accumulate, void* stream) {
-    SN_REQUIRE(x && y && d_out && d_im, "interp_bwd: null pointer");
+                       int accumulate, void* workspace, void* stream) {
+    SN_REQUIRE(x && y && d_out && d_im && workspace, "interp_bwd: null pointer");
     SN_REQUIRE(N > 0 && N <= 65535 && H > 0 && W > 0 && C > 0, "interp_bwd: bad shape");
+    SN_REQUIRE(((uintptr_t)workspace & 7) == 0, "interp_bwd: workspace must be 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (!accumulate && hipMemsetAsync(d_im, 0, sizeof(float) * (size_t)N * H * W * C, st) != hipSuccess) {
+    const long total = (long)N * H * W * C;
+    if (hipMemsetAsync(workspace, 0, sizeof(sn_u64) * (size_t)total, st) != hipSuccess) {
         stabnet_set_error("interp_bwd: memset failed");
         return STABNET_ERR_LAUNCH;
     }
     dim3 grid(cdiv(W, 256), cdiv(H, 4), N);
-    interp_bwd_kernel<<<grid, 256, 0, st>>>(x, y, d_out, H, W, C, d_im);
+    interp_bwd_kernel<<<grid, 256, 0, st>>>(x, y, d_out, H, W, C, static_cast<sn_u64*>(workspace));
     SN_LAUNCH_CHECK("interp_bwd_kernel");
+    fix_to_float_kernel<<<cdiv(total, 256), 256, 0, st>>>(static_cast<const sn_u64*>(workspace), total, d_im, accumulate);
+    SN_LAUNCH_CHECK("fix_to_float_kernel");
     return STABNET_OK;
 }
 
@@ -492,18 +553,18 @@ int stabnet_axpb(const float* x, float a, float b, long n, float* y, void* strea
 }
 
 /* Masked MSE used by img_loss (s_net_bundle_nobm.py:347-352; m2 = NULL) and temp_loss (train_bundle_nobm.py:110-125;
- * m2 = interp(1-black2)): sums [N,2] = {sum((a-b)m)^2, sum m}, m = (1-black)*m2.  value = sum_n s0/(s1+1e-8)/batch_size. */
+ * m2 = interp(1-black2)): sums [N,2] = {sum((a-b)m)^2, sum m}, m = (1-black)*m2.  value = sum_n s0/(s1+1e-8)/batch_size.
+ * workspace: stabnet_masked_mse_workspace_bytes(N) (block partials). */
+size_t stabnet_masked_mse_workspace_bytes(int N) { return (size_t)std::max(N, 0) * 512 * 2 * sizeof(float); }
 int stabnet_masked_mse_sums(const float* a, const float* b, const float* black, const float* m2, int N, long hw,
-                            float* sums, void* stream) {
-    SN_REQUIRE(a && b && black && sums && N > 0 && N <= 65535 && hw > 0, "masked_mse_sums: bad arguments");
+                            float* sums, void* workspace, void* stream) {
+    SN_REQUIRE(a && b && black && sums && workspace && N > 0 && N <= 65535 && hw > 0, "masked_mse_sums: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * N, st) != hipSuccess) {
-        stabnet_set_error("masked_mse_sums: memset failed");
-        return STABNET_ERR_LAUNCH;
-    }
     const int bx = (int)std::min<long>(cdiv(hw, 256 * 8), 512);
-    masked_mse_sums_kernel<<<dim3(bx, N), 256, 0, st>>>(a, b, black, m2, hw, sums);
+    masked_mse_sums_kernel<<<dim3(bx, N), 256, 0, st>>>(a, b, black, m2, hw, static_cast<float*>(workspace));
     SN_LAUNCH_CHECK("masked_mse_sums_kernel");
+    masked_mse_finalize_kernel<<<N, 64, 0, st>>>(static_cast<const float*>(workspace), bx, sums);
+    SN_LAUNCH_CHECK("masked_mse_finalize_kernel");
     return STABNET_OK;
 }
 
@@ -517,13 +578,15 @@ int stabnet_masked_mse_grad(const float* a, const float* b, const float* black, 
     return STABNET_OK;
 }
 
-/* feature loss value per sample + gradient scattered into d_xmap/d_ymap (zeroed here when given).
- * gcoef = dL/d(feature_loss) / N (the reduce_mean over the batch). */
+/* feature loss value per sample + its gradient wrt the maps as signed counts scattered into d_xmap/d_ymap (zeroed here
+ * when given) and the per-sample factor dscale [N] = gcoef / max(sum mask, 1) (gcoef = dL/d(feature_loss) / N, the
+ * reduce_mean over the batch): d loss / d x_map = d_xmap * dscale[n]. */
 int stabnet_feature_loss(const float* matches, const float* mask, const float* x_map, const float* y_map, int N, int H,
-                         int W, int max_matches, float gcoef, float* value, float* d_xmap, float* d_ymap,
+                         int W, int max_matches, float gcoef, float* value, float* d_xmap, float* d_ymap, float* dscale,
                          float* warped, void* stream) {
     SN_REQUIRE(matches && mask && x_map && y_map && value && N > 0 && max_matches > 0, "feature_loss: bad arguments");
     SN_REQUIRE((d_xmap == nullptr) == (d_ymap == nullptr), "feature_loss: d_xmap and d_ymap go together");
+    SN_REQUIRE(d_xmap == nullptr || dscale != nullptr, "feature_loss: the map gradient needs dscale");
     hipStream_t st = (hipStream_t)stream;
     if (d_xmap != nullptr) {
         if (hipMemsetAsync(d_xmap, 0, sizeof(float) * (size_t)N * H * W, st) != hipSuccess ||
@@ -532,7 +595,8 @@ int stabnet_feature_loss(const float* matches, const float* mask, const float* x
             return STABNET_ERR_LAUNCH;
         }
     }
-    feature_loss_kernel<<<N, 256, 0, st>>>(matches, mask, x_map, y_map, H, W, max_matches, gcoef, value, d_xmap, d_ymap, warped);
+    feature_loss_kernel<<<N, 256, 0, st>>>(matches, mask, x_map, y_map, H, W, max_matches, gcoef, value, d_xmap, d_ymap, warped,
+                                          dscale);
     SN_LAUNCH_CHECK("feature_loss_kernel");
     return STABNET_OK;
 }
@@ -543,7 +607,7 @@ int stabnet_feature_loss(const float* matches, const float* mask, const float* x
 int stabnet_mesh_losses(const float* theta, const float* d_pts2_warp, int N, int grid_h, int grid_w, float do_crop_rate,
                         float id_mul, float w_id, float w_dist, float w_cons, float use_black, float w_black,
                         float* losses4, float* d_theta, void* stream) {
-    SN_REQUIRE(theta && losses4 && d_theta, "mesh_losses: null pointer");
+    SN_REQUIRE(theta && losses4, "mesh_losses: null pointer");
     SN_REQUIRE(N > 0 && N <= 64 && (grid_h + 1) * (grid_w + 1) <= 81 && do_crop_rate > 0.f, "mesh_losses: bad shape");
     const size_t lds = (size_t)N * 4 * (grid_h + 1) * (grid_w + 1) * sizeof(float);
     if (lds <= 60 * 1024)

@@ -99,5 +99,5 @@ def augment_pairs(stable, unstable, flow, matches1, n1, matches2, n2, para, jitt
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     _lib.call("stabnet_augment_pairs", ptr(stable), ptr(unstable), ptr(flow_d), ptr(m1), ptr(c1), ptr(m2), ptr(c2), ptr(para_d),
               ptr(jit_d), ptr(Hs_d), N, H, W, bc, M, float(cfg.random_crop_rate), ptr(x1), ptr(y1), ptr(x2), ptr(y2), ptr(flow_o),
-              ptr(fm1), ptr(mk1), ptr(fm2), ptr(mk2), ptr(ws), nbytes, stream_ptr())
+              ptr(fm1), ptr(mk1), ptr(fm2), ptr(mk2), ptr(ws), nbytes, stream_ptr(dev), device=dev)
     return x1, y1, x2, y2, flow_o, fm1, mk1, fm2, mk2

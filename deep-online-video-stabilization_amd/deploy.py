@@ -16,9 +16,10 @@ from .regressor import Regressor
 class Profiler:
     """Per-launch HIP-event records taken inside the library (bench.py roofline leg)."""
 
-    def __init__(self, max_records: int = 65536):
+    def __init__(self, max_records: int = 65536, device=None):
         self._h = ctypes.c_void_p()
         self.overhead_ms = 0.0
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         _lib.call("stabnet_prof_create", ctypes.byref(self._h), max_records)
 
     @property
@@ -34,7 +35,7 @@ class Profiler:
         from ._tensor import stream_ptr
         self.reset()
         for _ in range(n):
-            _lib.call("stabnet_prof_record_empty", self._h, stream_ptr())
+            _lib.call("stabnet_prof_record_empty", self._h, stream_ptr(self.device), device=self.device)
         ms = sorted(r[1] for r in self.records())
         self.reset()
         self.overhead_ms = ms[len(ms) // 2]
@@ -98,7 +99,8 @@ class StabNetStream:
         self.Hs = f(streams, cfg.grid_h, cfg.grid_w, 9)
         self.frame_fb = f(streams, H, W)
         self.cur = f(streams, H, W)                       # fixed-address staging buffer of the current frame
-        self.head_dev = torch.zeros(1, dtype=torch.int32, device=dev)     # ring head lives on the device (graph replay)
+        self.head_dev = torch.zeros(2, dtype=torch.int32, device=dev)     # {ring head, ticket}: on the device (graph replay)
+        self.all_black = None                             # optional int32 [S,H,W]: += round(black) per refine pass (:291)
         self.use_graph = use_graph
         self._graph = None
         self.started = False
@@ -106,22 +108,31 @@ class StabNetStream:
     @property
     def head(self) -> int:
         """Ring slot the NEXT frame's push writes (host read-back; synchronises)."""
-        return int(self.head_dev.item())
+        return int(self.head_dev[0].item())
 
     def start(self, first_frame: torch.Tensor):
         first = dev_f32(first_frame, "first_frame").reshape(self.S, self.H, self.W)
         _lib.call("stabnet_ring_init", ptr(self.frames_ring), ptr(self.masks_ring), ptr(first), self.S, self.depth,
-                  self.H, self.W, stream_ptr())
+                  self.H, self.W, stream_ptr(self.reg.device), device=self.reg.device)
         self.head_dev.zero_()
+        if self.all_black is not None:
+            self.all_black.zero_()
         self.started = True
+
+    def track_black(self, enable: bool = True):
+        """Accumulate all_black (deploy_bundle.py:234,291) on the device for the crop search; reset by start()."""
+        self.all_black = (torch.zeros((self.S, self.H, self.W), dtype=torch.int32, device=self.reg.device) if enable else None)
+        self._graph = None
+        return self.all_black
 
     def _enqueue(self, prof=None):
         r = self.reg
         _lib.call("stabnet_deploy_frame", r.plan.handle, ptr(r.params), ptr(r.fold), ptr(self.frames_ring),
                   ptr(self.masks_ring), self.depth, ptr(self.head_dev), self._lags_c, len(self.lags), ptr(self.cur),
                   self.refine, self.cfg.grid_h, self.cfg.grid_w, self.cfg.do_crop_rate, ptr(self.theta), ptr(self.out_img),
-                  ptr(self.black), ptr(self.x_map), ptr(self.y_map), ptr(self.Hs), ptr(self.frame_fb),
-                  ptr(r.workspace), r.workspace.numel(), stream_ptr(), prof.handle if prof is not None else 0)
+                  ptr(self.black), ptr(self.x_map), ptr(self.y_map), ptr(self.Hs), ptr(self.frame_fb), ptr(self.all_black),
+                  ptr(r.workspace), r.workspace.numel(), stream_ptr(r.device), prof.handle if prof is not None else 0,
+                  device=r.device)
 
     def step(self, cur: torch.Tensor, prof: Profiler = None):
         if not self.started:
@@ -133,9 +144,10 @@ class StabNetStream:
                 self._enqueue()                  # this frame runs eagerly (also loads modules / sets kernel attributes)
                 torch.cuda.synchronize()
                 try:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):        # capture records only; nothing executes here
-                        self._enqueue()
+                    with torch.cuda.device(self.reg.device):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):    # capture records only; nothing executes here
+                            self._enqueue()
                     self._graph = g
                 except Exception as e:               # capture unsupported on this runtime: stay eager, say so once
                     import sys

@@ -38,7 +38,7 @@ def conv2d(x, w_ohwi, bias=None, in_scale=None, in_shift=None, residual=None, re
     rH, rW = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)
     _lib.call("stabnet_conv2d_fwd_ex", ptr(x), ptr(w), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(residual), rH, rW,
               res_stride, ptr(out_scale), ptr(out_shift), ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad,
-              int(relu_out), ptr(ws), ws_bytes, stream_ptr())
+              int(relu_out), ptr(ws), ws_bytes, stream_ptr(x.device), device=x.device)
     return y
 
 
@@ -51,8 +51,10 @@ def conv2d_wgrad(x, dy, w_shape, in_scale=None, in_shift=None, stride=1, pad=0, 
     assert Cw == Cin
     if dw is None:
         dw = torch.zeros(w_shape, dtype=torch.float32, device=x.device)
+    nbytes = _lib.lib().stabnet_conv2d_wgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     _lib.call("stabnet_conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(in_scale), ptr(in_shift), N, H, W, Cin, Cout, KH, KW,
-              stride, pad, stream_ptr())
+              stride, pad, ptr(ws), nbytes, stream_ptr(x.device), device=x.device)
     return dw
 
 
@@ -66,5 +68,5 @@ def conv2d_dgrad(dy, w_ohwi, x_shape, stride=1, pad=0, residual=None):
     nbytes = L.stabnet_conv2d_dgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
     _lib.call("stabnet_conv2d_dgrad", ptr(dy), ptr(w), ptr(dx), ptr(residual), N, H, W, Cin, Cout, KH, KW, stride, pad,
-              ptr(ws), nbytes, stream_ptr())
+              ptr(ws), nbytes, stream_ptr(dy.device), device=dy.device)
     return dx

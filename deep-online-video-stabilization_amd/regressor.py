@@ -97,11 +97,12 @@ class Regressor:
         self.params = torch.from_numpy(np.ascontiguousarray(flat)).to(self.device)
         self.fold = torch.empty(int(_lib.lib().stabnet_net_fold_floats(self.plan.handle)), dtype=torch.float32, device=self.device)
         self.workspace = torch.empty(self.plan.workspace_bytes, dtype=torch.uint8, device=self.device)
+        self._train = None                   # (plan, workspace, theta) of the is_training=True branch, made on first use
         self.refold()
 
     def refold(self):
         _lib.call("stabnet_net_fold_bn", self.plan.handle, ptr(self.params), ptr(self.fold), self.cfg.bn_eps,
-                  stream_ptr())
+                  stream_ptr(self.device), device=self.device)
 
     def forward(self, x_tensor: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         x = dev_f32(x_tensor, "x_tensor")
@@ -110,10 +111,28 @@ class Regressor:
             tuple(x.shape), (p.N, p.H, p.W, self.cfg.in_ch))
         theta = out if out is not None else empty((p.N, self.cfg.n_theta), x)
         _lib.call("stabnet_backbone_fwd_infer", p.handle, ptr(self.params), ptr(self.fold), ptr(x), ptr(theta),
-                  ptr(self.workspace), self.workspace.numel(), stream_ptr(), 0)
+                  ptr(self.workspace), self.workspace.numel(), stream_ptr(self.device), 0, device=self.device)
         return theta
 
     __call__ = forward
+
+    def forward_train(self, x_tensor: torch.Tensor) -> torch.Tensor:
+        """get_resnet(..., is_training=True) (s_net_bundle_nobm.py:301): batch-statistics BN; the moving averages held in
+        `self.params` are updated with cfg.bn_decay (slim UPDATE_OPS, :355-356).  Activations stay in the training
+        workspace (what stabnet_tower_bwd consumes).  Call refold() before the next inference-mode forward."""
+        x = dev_f32(x_tensor, "x_tensor")
+        p = self.plan
+        assert tuple(x.shape) == (p.N, p.H, p.W, self.cfg.in_ch), "x_tensor %s != plan %s" % (
+            tuple(x.shape), (p.N, p.H, p.W, self.cfg.in_ch))
+        if self._train is None:
+            tp = NetPlan(p.N, p.H, p.W, self.cfg, keep_activations=True)
+            nbytes = _lib.lib().stabnet_net_train_workspace_bytes(tp.handle)
+            self._train = (tp, torch.empty(nbytes, dtype=torch.uint8, device=self.device))
+        tp, ws = self._train
+        theta = empty((p.N, self.cfg.n_theta), x)
+        _lib.call("stabnet_tower_fwd_train", tp.handle, ptr(self.params), ptr(x), ptr(theta), ptr(ws), ws.numel(),
+                  self.cfg.bn_eps, self.cfg.bn_decay, stream_ptr(self.device), 0, device=self.device)
+        return theta
 
     def activation(self, name: str) -> torch.Tensor:
         """Debug tap (plan built with keep_activations=True): a view into the workspace, NHWC."""
@@ -125,9 +144,14 @@ class Regressor:
 
 
 def get_resnet(x_tensor, reuse=None, is_training=False, x_batch_size=None, *, regressor: Regressor):
-    """s_net_bundle_nobm.py:250-264 -> (theta, id_loss, id2_loss); id2_loss = mean|theta| * id_mul (:263)."""
-    if is_training:
-        raise NotImplementedError("batch-statistics BN lives in stabnet_amd.train")
-    theta = regressor(x_tensor)
-    id2 = theta.abs().mean() * regressor.cfg.id_mul
+    """s_net_bundle_nobm.py:250-264 -> (theta, id_loss, id2_loss); id2_loss = mean|theta| * id_mul (:263), and the
+    reference returns it for both (`return theta, id2_loss, id2_loss`, :264).  is_training=True is the batch-statistics
+    branch the reference builds at :301; False the moving-average branch of :302 (what deploy runs).  `reuse` and
+    `x_batch_size` are graph-construction arguments of TF with no counterpart here (the batch is the plan's N)."""
+    theta = regressor.forward_train(x_tensor) if is_training else regressor(x_tensor)
+    cfg = regressor.cfg
+    losses4 = empty((4,), theta)
+    _lib.call("stabnet_mesh_losses", ptr(theta), 0, theta.shape[0], cfg.grid_h, cfg.grid_w, cfg.do_crop_rate, cfg.id_mul,
+              0.0, 0.0, 0.0, 0.0, 0.0, ptr(losses4), 0, stream_ptr(theta.device), device=theta.device)
+    id2 = losses4[0]
     return theta, id2, id2

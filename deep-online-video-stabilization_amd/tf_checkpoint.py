@@ -260,6 +260,43 @@ def load_stabnet_variables(prefix: str):
     return params, extras
 
 
+def checkpoint_format(prefix: str) -> str:
+    """'v2' : `<prefix>.index` is a tensor-bundle table (what tf.train.Saver writes since TF 1.0 and what this module reads);
+    'v1' : `<prefix>` itself is a table file -- the older single-file format slim distributes `resnet_v2_50.ckpt` in
+           (SavedTensorSlices values; NOT read here);
+    'none': neither exists;  'unknown': a file exists but is not a table."""
+    def is_table(path):
+        try:
+            with open(path, "rb") as f:
+                f.seek(0, os.SEEK_END)
+                if f.tell() < 48:
+                    return False
+                f.seek(-8, os.SEEK_END)
+                return struct.unpack("<Q", f.read(8))[0] == _MAGIC
+        except OSError:
+            return False
+    if os.path.isfile(prefix + ".index"):
+        return "v2" if is_table(prefix + ".index") else "unknown"
+    if os.path.isfile(prefix):
+        return "v1" if is_table(prefix) else "unknown"
+    return "none"
+
+
+def try_load_imagenet_resnet(prefix: str):
+    """-> (variables or None, note).  Never raises for a missing / unsupported file: the training driver then keeps its
+    seeded initialiser and prints the note (train_bundle_nobm.py:184-191 is an optional warm start)."""
+    fmt = checkpoint_format(prefix)
+    if fmt == "v2":
+        return load_imagenet_resnet(prefix), "initialised from the V2 checkpoint %s" % prefix
+    if fmt == "v1":
+        return None, ("%s is a V1 (single-file) TensorFlow checkpoint, which this build does not read: convert it once with "
+                      "TensorFlow (`tf.train.Saver(write_version=2)`) or to an .npz of TF variable names; continuing from the "
+                      "seeded initialiser" % prefix)
+    if fmt == "unknown":
+        return None, "%s exists but is not a TensorFlow checkpoint table; continuing from the seeded initialiser" % prefix
+    return None, "%s not found; the backbone starts from the seeded initialiser" % prefix
+
+
 def load_imagenet_resnet(prefix: str):
     """train_bundle_nobm.py:184-191,101-102: the ImageNet `resnet_v2_50.ckpt` initialises every variable under
     `stable_net/resnet/` except `resnet_v2_50/conv1` (13 input channels instead of 3) and the `fc` head; a variable

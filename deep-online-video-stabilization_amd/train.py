@@ -1,8 +1,12 @@
 """Host side of the training step (train_bundle_nobm.py:107-160,216-236,327-346): two siamese towers sharing the
 weights, the temporal loss through the flow sampler, the loss schedule gates, Adam with the staircase learning rate,
-and -- new, the reference is single-device -- data parallelism: one process per GPU, samples sharded across ranks,
-local BN statistics, gradient all-reduce over RCCL (torch.distributed "nccl") overlapped with the other tower's
-backward.  Every tensor op is a C-ABI kernel; torch allocates, holds pointers, owns the streams and the collective."""
+and -- new, the reference is single-device -- data parallelism: one process per GPU, samples sharded across
+ranks, local BN statistics, ONE 121.6 MB gradient per step (both towers accumulate into the same buffer) all-reduced over
+RCCL (torch.distributed "nccl") in reverse layer order: tower 1's backward runs in four stages (FC head + block4, block3,
+block2, block1 + stem) and each stage's parameter bucket goes to the communication stream as soon as that stage is
+enqueued, so the collective of the big late layers overlaps the backward of the early ones.
+Every tensor op is a C-ABI kernel; torch allocates, holds pointers, owns the streams and the collective.  The step is
+reproducible bit for bit (no order-dependent float atomics anywhere on the path)."""
 from __future__ import annotations
 
 import ctypes
@@ -31,8 +35,10 @@ def loss_gates(i: int, cfg: Config):
 
 
 def learning_rate(step: int, cfg: Config) -> float:
-    """tf.train.exponential_decay(..., staircase=True) (train_bundle_nobm.py:155-158)."""
-    return cfg.initial_learning_rate * (0.1 ** (step // cfg.step_size))
+    """tf.train.exponential_decay(..., decay_rate=0.1, staircase=True) (train_bundle_nobm.py:155-158), in float32 as TF
+    computes it: lr0 * pow(0.1, floor(step / step_size))."""
+    p = np.float32(np.floor(np.float32(step) / np.float32(cfg.step_size)))
+    return float(np.float32(cfg.initial_learning_rate) * np.float32(np.power(np.float32(0.1), p)))
 
 
 class Trainer:
@@ -48,7 +54,7 @@ class Trainer:
         self.params = torch.from_numpy(np.ascontiguousarray(flat)).to(dev)
         nt = self.plan.n_trainable
         self.nt = nt
-        self.grads = [torch.zeros(nt, dtype=torch.float32, device=dev) for _ in range(2)]      # one buffer per tower
+        self.grads = torch.zeros(nt, dtype=torch.float32, device=dev)        # ONE buffer: both towers accumulate into it
         self.adam_m = torch.zeros(nt, dtype=torch.float32, device=dev)
         self.adam_v = torch.zeros(nt, dtype=torch.float32, device=dev)
         L = _lib.lib()
@@ -67,34 +73,64 @@ class Trainer:
         self.seg_len = torch.tensor(lens, dtype=torch.int64, device=dev)
         self.seg_coef = torch.tensor(coefs, dtype=torch.float32, device=dev)
         self.regu_val = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.wd_ws = torch.empty(64 * len(offs), dtype=torch.float32, device=dev)
         self.global_step = 0
         self.pg = process_group
         self.world = world_size
         self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
         self.last = None
         self.prof = None                                        # deploy.Profiler: per-launch HIP events (bench only)
+        # gradient buckets in the order backward completes them (reverse layer order) + the BN gamma/beta sections
+        self.n_stages = L.stabnet_net_num_grad_stages()
+        lo, hi = ctypes.c_long(), ctypes.c_long()
+        self.buckets = []
+        for k in range(self.n_stages):
+            _lib.call("stabnet_net_grad_bucket", self.plan.handle, k, ctypes.byref(lo), ctypes.byref(hi))
+            self.buckets.append((lo.value, hi.value))
+        _lib.call("stabnet_net_bn_grad_range", self.plan.handle, ctypes.byref(lo), ctypes.byref(hi))
+        self.bn_bucket = (lo.value, hi.value)
+        assert sorted(self.buckets + [self.bn_bucket])[0][0] == 0 and sum(b - a for a, b in self.buckets + [self.bn_bucket]) == nt
+        self.comm_timing = None               # bench: list of (start, end) event pairs on the comm stream, one per bucket
 
     # ------------------------------------------------------------------------------------------------------
     def _tower_fwd(self, k: int, x):
         _lib.call("stabnet_tower_fwd_train", self.plan.handle, ptr(self.params), ptr(x), ptr(self.theta[k]),
-                  ptr(self.ws[k]), self.ws_bytes, self.cfg.bn_eps, self.cfg.bn_decay, stream_ptr(),
-                  self.prof.handle if self.prof is not None else 0)
+                  ptr(self.ws[k]), self.ws_bytes, self.cfg.bn_eps, self.cfg.bn_decay, stream_ptr(self.device),
+                  self.prof.handle if self.prof is not None else 0, device=self.device)
         return self.theta[k]
 
-    def _tower_bwd(self, k: int, d_theta):
-        _lib.call("stabnet_tower_bwd", self.plan.handle, ptr(self.params), ptr(d_theta), ptr(self.grads[k]),
-                  ptr(self.ws[k]), self.ws_bytes, stream_ptr(), self.prof.handle if self.prof is not None else 0)
-
-    def _allreduce_async(self, k: int):
-        """Sum tower k's gradient buffer over ranks on the communication stream (overlaps the next backward)."""
-        if self.world <= 1:
+    def _tower_bwd(self, k: int, d_theta, reduce_buckets: bool = False):
+        """Backward of tower k into the shared gradient buffer.  reduce_buckets (the LAST tower, world > 1): stage by stage,
+        with each finished bucket handed to the communication stream (reverse layer order, overlapping what is left)."""
+        prof = self.prof.handle if self.prof is not None else 0
+        if not (reduce_buckets and self.world > 1):
+            _lib.call("stabnet_tower_bwd", self.plan.handle, ptr(self.params), ptr(d_theta), ptr(self.grads),
+                      ptr(self.ws[k]), self.ws_bytes, stream_ptr(self.device), prof, device=self.device)
             return
+        for stage in range(self.n_stages):
+            _lib.call("stabnet_tower_bwd_stage", self.plan.handle, ptr(self.params), ptr(d_theta), ptr(self.grads),
+                      ptr(self.ws[k]), self.ws_bytes, stage, stream_ptr(self.device), prof, device=self.device)
+            self._allreduce_async(*self.buckets[stage])
+        self._allreduce_async(*self.bn_bucket)
+
+    def _allreduce_async(self, lo: int, hi: int):
+        """Sum grads[lo:hi] over ranks on the communication stream, ordered after everything enqueued so far."""
         import torch.distributed as dist
-        self.comm_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.comm_stream):
-            # a few large buckets: xGMI is point-to-point, rings are per-link bound -> few big messages
-            for lo, hi in parallel.bucket_bounds(self.nt, 4):
-                dist.all_reduce(self.grads[k][lo:hi], group=self.pg)
+        cs = self.comm_stream
+        cs.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(cs):
+            if self.comm_timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cs)
+            # xGMI is point-to-point, rings are per-link bound -> one large message per bucket, not many small ones
+            dist.all_reduce(self.grads[lo:hi], group=self.pg)
+            if self.comm_timing is not None:
+                e1.record(cs)
+                self.comm_timing.append((e0, e1, (hi - lo) * 4))
+
+    def grad_flat(self) -> torch.Tensor:
+        """The step's gradient (both towers; summed over ranks when world > 1), trainable layout."""
+        return self.grads
 
     def forward_backward(self, batch: dict, gates: dict = None, apply_update: bool = True):
         """One optimiser step on a batch dict (x1,y1,x2,y2,flow,matches1,mask1,matches2,mask2), device tensors.
@@ -104,19 +140,18 @@ class Trainer:
         to = float(g["use_theta_only"])
         live = 1.0 - to
         cur = 2 * cfg.before_ch if cfg.input_mask else cfg.before_ch
-        for gb in self.grads:
-            gb.zero_()
+        self.grads.zero_()
         self.regu_val.zero_()
         towers = []
         for k, s in enumerate(("1", "2")):
             x = dev_f32(batch["x" + s])
             theta = self._tower_fwd(k, x)
-            frame = x[..., cur:cur + 1].contiguous()
+            frame = warp.slice_channel(x, cur)                                    # x = x_tensor[..., 12:13], s_net:281
             r = warp.warp_from_theta(frame, theta, cfg)
             r["frame"] = frame
             towers.append(r)
         flow = dev_f32(batch["flow"])
-        fx, fy = flow[..., 0].contiguous(), flow[..., 1].contiguous()
+        fx, fy = warp.slice_channel(flow, 0), warp.slice_channel(flow, 1)
         # ---- loss values (forward)
         img_sums = [train_ops.masked_mse_sums(t["output"], dev_f32(batch["y" + s]), t["black_pix"])
                     for t, s in zip(towers, ("1", "2"))]
@@ -137,32 +172,32 @@ class Trainer:
         _, g_o2w = train_ops.masked_mse_grad(towers[0]["output"], o2w, towers[0]["black_pix"], nb2w, t_sums, c_tmp,
                                              ga=g_out[0], accumulate_a=True, want_gb=True)
         train_ops.interp_bwd(fx, fy, g_o2w, d_im=g_out[1])
-        # ---- through the warp and the mesh losses to d theta, then the towers (tower 2 first: its all-reduce overlaps
-        # tower 1's backward)
+        # ---- through the warp and the mesh losses to d theta, then the towers: tower 2 first (plain accumulation), then
+        # tower 1 stage by stage with the finished buckets going to the collective
         w_id = cfg.theta_mul + cfg.grid_theta_mul
         mesh = [None, None]
         for k in (1, 0):
             t = towers[k]
             d_pts2 = train_ops.transformer_bwd(t["pts2"], t["Hs"], t["frame"], t["x_map"], t["y_map"], g_out[k],
-                                               feats[k][1], feats[k][2], cfg)
+                                               feats[k][1], feats[k][2], cfg, dmap_scale=feats[k][4])
             losses4, d_theta = train_ops.mesh_losses(self.theta[k], d_pts2, cfg, w_id, live * cfg.distortion_mul,
                                                      live * cfg.consistency_mul, float(g["use_black_loss"]),
                                                      live * cfg.black_mul)
             mesh[k] = losses4
-            self._tower_bwd(k, d_theta)
-            self._allreduce_async(k)
+            self._tower_bwd(k, d_theta, reduce_buckets=(k == 0))
         if self.world > 1:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         # regu_loss is counted once per tower (train_bundle_nobm.py:142): gradient coefficient 2 * regu_mul * live
         # (times world: the summed gradient is divided by world in the Adam kernel, the regulariser is not a rank sum)
-        _lib.call("stabnet_weight_decay", ptr(self.params), ptr(self.grads[0]), ptr(self.seg_off), ptr(self.seg_len),
+        _lib.call("stabnet_weight_decay", ptr(self.params), ptr(self.grads), ptr(self.seg_off), ptr(self.seg_len),
                   ptr(self.seg_coef), self.seg_off.numel(), 2.0 * cfg.regu_mul * live * self.world, ptr(self.regu_val),
-                  stream_ptr())
+                  ptr(self.wd_ws), stream_ptr(self.device), device=self.device)
         self.global_step += 1
         if apply_update:
             lr = learning_rate(self.global_step - 1, cfg)
-            _lib.call("stabnet_adam_step", ptr(self.params), ptr(self.grads[0]), ptr(self.grads[1]), ptr(self.adam_m),
-                      ptr(self.adam_v), self.nt, lr, 0.9, 0.999, 1e-8, self.global_step, 1.0 / self.world, stream_ptr())
+            _lib.call("stabnet_adam_step", ptr(self.params), ptr(self.grads), 0, ptr(self.adam_m),
+                      ptr(self.adam_v), self.nt, lr, 0.9, 0.999, 1e-8, self.global_step, 1.0 / self.world,
+                      stream_ptr(self.device), device=self.device)
         self.last = {"towers": towers, "mesh": mesh, "img_sums": img_sums, "t_sums": t_sums, "feats": feats, "gates": g,
                      "batch": batch}
         return self.last
@@ -219,8 +254,23 @@ class Trainer:
         return d
 
     def state_dict(self) -> dict:
+        """Everything a resume needs.  Data parallel: trainables, Adam moments and the step are identical on every rank
+        (same summed gradient, same update); the BN MOVING statistics are NOT -- every rank tracks its own shard's batch
+        statistics (local BN) -- so call sync_moving_stats() first to checkpoint their rank mean."""
         return {"params": self.params.cpu().numpy(), "adam_m": self.adam_m.cpu().numpy(), "adam_v": self.adam_v.cpu().numpy(),
                 "global_step": self.global_step}
+
+    def sync_moving_stats(self):
+        """Average the BN moving means / variances over ranks in place (no-op for one process).  The moving statistics
+        are exponential averages of per-shard batch moments; their rank mean is the average over the global batch's
+        shards, which is what a single-process run with `world` x more steps of the same decay would track in expectation.
+        Done at checkpoint time only (train_bundle_nobm.py:271-272), never inside the step."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        tail = self.params[self.nt:]
+        dist.all_reduce(tail, group=self.pg)
+        tail.div_(self.world)
 
     def load_state_dict(self, sd: dict):
         self.params.copy_(torch.from_numpy(sd["params"]))

@@ -8,14 +8,15 @@ from ._tensor import dev_f32, empty, ptr, stream_ptr
 from .config import Config, v2_93
 
 
-def transformer_bwd(pts2, Hs, U, x_map, y_map, d_out=None, d_xmap=None, d_ymap=None, cfg: Config = v2_93):
+def transformer_bwd(pts2, Hs, U, x_map, y_map, d_out=None, d_xmap=None, d_ymap=None, cfg: Config = v2_93, dmap_scale=None):
+    """d_xmap / d_ymap are multiplied per sample by dmap_scale [N] when given (feature_loss returns counts + that scale)."""
     U = dev_f32(U, "U")
     N, H, W, C = U.shape
     d_pts2 = empty((N, cfg.grid_h + 1, cfg.grid_w + 1, 2), U)
-    ws = empty((N * cfg.grid_h * cfg.grid_w * 8,), U, dtype=torch.float64)
+    ws = empty((N * cfg.grid_h * cfg.grid_w * 8,), U, dtype=torch.int64)
     _lib.call("stabnet_transformer_bwd", ptr(dev_f32(pts2)), ptr(dev_f32(Hs)), ptr(U), ptr(dev_f32(x_map)),
-              ptr(dev_f32(y_map)), ptr(d_out), ptr(d_xmap), ptr(d_ymap), N, H, W, C, cfg.grid_h, cfg.grid_w, ptr(d_pts2),
-              ptr(ws), stream_ptr())
+              ptr(dev_f32(y_map)), ptr(d_out), ptr(d_xmap), ptr(d_ymap), ptr(dmap_scale), N, H, W, C, cfg.grid_h, cfg.grid_w, ptr(d_pts2),
+              ptr(ws), stream_ptr(U.device), device=U.device)
     return d_pts2
 
 
@@ -26,15 +27,16 @@ def interp_bwd(x, y, d_out, d_im=None):
     acc = d_im is not None
     if d_im is None:
         d_im = empty((N, H, W, C), d_out)
-    _lib.call("stabnet_interp_bwd", ptr(dev_f32(x)), ptr(dev_f32(y)), ptr(d_out), N, H, W, C, ptr(d_im), int(acc),
-              stream_ptr())
+    ws = empty((N * H * W * C,), d_out, dtype=torch.int64)           # fixed-point accumulators of the scatter
+    _lib.call("stabnet_interp_bwd", ptr(dev_f32(x)), ptr(dev_f32(y)), ptr(d_out), N, H, W, C, ptr(d_im), int(acc), ptr(ws),
+              stream_ptr(d_out.device), device=d_out.device)
     return d_im
 
 
 def axpb(x, a, b):
     x = dev_f32(x)
     y = torch.empty_like(x)
-    _lib.call("stabnet_axpb", ptr(x), float(a), float(b), x.numel(), ptr(y), stream_ptr())
+    _lib.call("stabnet_axpb", ptr(x), float(a), float(b), x.numel(), ptr(y), stream_ptr(x.device), device=x.device)
     return y
 
 
@@ -43,8 +45,9 @@ def masked_mse_sums(a, b, black, m2=None):
     N = a.shape[0]
     hw = a.numel() // N
     sums = empty((N, 2), a)
-    _lib.call("stabnet_masked_mse_sums", ptr(a), ptr(dev_f32(b)), ptr(dev_f32(black)), ptr(m2), N, hw, ptr(sums),
-              stream_ptr())
+    ws = torch.empty(_lib.lib().stabnet_masked_mse_workspace_bytes(N), dtype=torch.uint8, device=a.device)
+    _lib.call("stabnet_masked_mse_sums", ptr(a), ptr(dev_f32(b)), ptr(dev_f32(black)), ptr(m2), N, hw, ptr(sums), ptr(ws),
+              stream_ptr(a.device), device=a.device)
     return sums
 
 
@@ -57,11 +60,12 @@ def masked_mse_grad(a, b, black, m2, sums, coef, ga=None, accumulate_a=False, wa
         accumulate_a = False
     gb = torch.empty_like(a) if want_gb else None
     _lib.call("stabnet_masked_mse_grad", ptr(a), ptr(dev_f32(b)), ptr(dev_f32(black)), ptr(m2), ptr(sums), float(coef),
-              N, hw, ptr(ga), int(accumulate_a), ptr(gb), stream_ptr())
+              N, hw, ptr(ga), int(accumulate_a), ptr(gb), stream_ptr(a.device), device=a.device)
     return ga, gb
 
 
 def feature_loss(matches, mask, x_map, y_map, gcoef=0.0, want_grad=False, want_warped=False):
+    """-> (value [N], d_xmap, d_ymap, warped, dscale): the map gradient is (d_xmap, d_ymap) [signed counts] * dscale[n]."""
     matches = dev_f32(matches)
     N, Mx, _ = matches.shape
     x_map = dev_f32(x_map)
@@ -70,9 +74,11 @@ def feature_loss(matches, mask, x_map, y_map, gcoef=0.0, want_grad=False, want_w
     dxm = empty((N, H, W), matches) if want_grad else None
     dym = empty((N, H, W), matches) if want_grad else None
     warped = empty((N, Mx, 2), matches) if want_warped else None
+    dscale = empty((N,), matches) if want_grad else None
     _lib.call("stabnet_feature_loss", ptr(matches), ptr(dev_f32(mask)), ptr(x_map), ptr(dev_f32(y_map)), N, H, W, Mx,
-              float(gcoef), ptr(value), ptr(dxm), ptr(dym), ptr(warped), stream_ptr())
-    return value, dxm, dym, warped
+              float(gcoef), ptr(value), ptr(dxm), ptr(dym), ptr(dscale), ptr(warped), stream_ptr(matches.device),
+              device=matches.device)
+    return value, dxm, dym, warped, dscale
 
 
 def mesh_losses(theta, d_pts2_warp, cfg: Config, w_id, w_dist, w_cons, use_black, w_black):
@@ -82,5 +88,5 @@ def mesh_losses(theta, d_pts2_warp, cfg: Config, w_id, w_dist, w_cons, use_black
     d_theta = torch.empty_like(theta)
     _lib.call("stabnet_mesh_losses", ptr(theta), ptr(d_pts2_warp), N, cfg.grid_h, cfg.grid_w, cfg.do_crop_rate,
               cfg.id_mul, float(w_id), float(w_dist), float(w_cons), float(use_black), float(w_black), ptr(losses),
-              ptr(d_theta), stream_ptr())
+              ptr(d_theta), stream_ptr(theta.device), device=theta.device)
     return losses, d_theta

@@ -21,11 +21,9 @@ def get_4_pts(theta: torch.Tensor, batch_size=None, cfg: Config = v2_93, with_Hs
     assert theta.shape[1] == (gh + 1) * (gw + 1) * 2
     pts2 = empty((N, gh + 1, gw + 1, 2), theta)
     Hs = empty((N, gh, gw, 9), theta)
-    _lib.call("stabnet_get_4_pts", ptr(theta), N, gh, gw, cfg.do_crop_rate, ptr(pts2), ptr(Hs), stream_ptr())
-    # pts1: per cell [xTL,xTR,xBL,xBR,yTL,yTR,yBL,yBR] (s_net_bundle_nobm.py:65-66) -- a re-packing of pts2
-    tl, tr = pts2[:, :-1, :-1], pts2[:, :-1, 1:]
-    bl, br = pts2[:, 1:, :-1], pts2[:, 1:, 1:]
-    pts1 = torch.stack([tl, tr, bl, br], dim=-1).reshape(N, gh, gw, 8)
+    pts1 = empty((N, gh, gw, 8), theta)      # per cell [xTL,xTR,xBL,xBR,yTL,yTR,yBL,yBR] (s_net_bundle_nobm.py:65-66)
+    _lib.call("stabnet_get_4_pts", ptr(theta), N, gh, gw, cfg.do_crop_rate, ptr(pts1), ptr(pts2), ptr(Hs),
+              stream_ptr(theta.device), device=theta.device)
     if with_Hs:
         return pts1, pts2, Hs
     return pts1, pts2
@@ -43,8 +41,9 @@ def transformer(U: torch.Tensor, theta: torch.Tensor, name="SpatialTransformer",
     ym = empty((N, H, W), U)
     Hs = empty((N, cfg.grid_h, cfg.grid_w, 9), U)
     _lib.call("stabnet_transformer_fwd", ptr(pts2), ptr(U), N, H, W, C, cfg.grid_h, cfg.grid_w, ptr(out), ptr(black),
-              ptr(xm), ptr(ym), ptr(Hs), stream_ptr())
-    img = torch.stack([xm, ym], dim=3)
+              ptr(xm), ptr(ym), ptr(Hs), stream_ptr(U.device), device=U.device)
+    img = empty((N, H, W, 2), U)                            # img = [x_map, y_map] (spatial_transformer3.py:295)
+    _lib.call("stabnet_interleave2", ptr(xm), ptr(ym), N * H * W, ptr(img), stream_ptr(U.device), device=U.device)
     if return_Hs:
         return out, black, img, Hs
     return out, black, img
@@ -63,8 +62,17 @@ def warp_from_theta(U: torch.Tensor, theta: torch.Tensor, cfg: Config = v2_93):
     Hs = empty((N, cfg.grid_h, cfg.grid_w, 9), U)
     pts2 = empty((N, cfg.grid_h + 1, cfg.grid_w + 1, 2), U)
     _lib.call("stabnet_warp_fwd", ptr(theta), ptr(U), N, H, W, C, cfg.grid_h, cfg.grid_w, cfg.do_crop_rate, ptr(out),
-              ptr(black), ptr(xm), ptr(ym), ptr(Hs), ptr(pts2), stream_ptr())
+              ptr(black), ptr(xm), ptr(ym), ptr(Hs), ptr(pts2), stream_ptr(U.device), device=U.device)
     return {"output": out, "black_pix": black, "x_map": xm, "y_map": ym, "Hs": Hs, "pts2": pts2}
+
+
+def slice_channel(x: torch.Tensor, c: int) -> torch.Tensor:
+    """x [..., C] -> x[..., c:c+1] as its own contiguous tensor (x_tensor[..., 12:13], s_net_bundle_nobm.py:281)."""
+    x = dev_f32(x, "x")
+    C = x.shape[-1]
+    out = empty(tuple(x.shape[:-1]) + (1,), x)
+    _lib.call("stabnet_slice_channel", ptr(x), x.numel() // C, C, int(c), ptr(out), stream_ptr(x.device), device=x.device)
+    return out
 
 
 def maps_from_Hs(U: torch.Tensor, Hs: torch.Tensor, cfg: Config = v2_93):
@@ -76,7 +84,7 @@ def maps_from_Hs(U: torch.Tensor, Hs: torch.Tensor, cfg: Config = v2_93):
     xm = empty((N, H, W), U)
     ym = empty((N, H, W), U)
     _lib.call("stabnet_maps_from_hs_fwd", ptr(Hs), ptr(U), N, H, W, C, cfg.grid_h, cfg.grid_w, ptr(out), ptr(black),
-              ptr(xm), ptr(ym), stream_ptr())
+              ptr(xm), ptr(ym), stream_ptr(U.device), device=U.device)
     return out, black, xm, ym
 
 
@@ -88,7 +96,7 @@ def interpolate(im: torch.Tensor, x: torch.Tensor, y: torch.Tensor, out_size=Non
     N, H, W, C = im.shape
     assert x.numel() == N * H * W and y.numel() == N * H * W
     out = empty((N, H, W, C), im)
-    _lib.call("stabnet_interp_fwd", ptr(im), ptr(x), ptr(y), N, H, W, C, ptr(out), stream_ptr())
+    _lib.call("stabnet_interp_fwd", ptr(im), ptr(x), ptr(y), N, H, W, C, ptr(out), stream_ptr(im.device), device=im.device)
     return out
 
 
@@ -108,7 +116,7 @@ def warpRevBundle2(img: torch.Tensor, x_map: torch.Tensor, y_map: torch.Tensor, 
     px = empty((N, H, W), xm) if return_maps else None
     py = empty((N, H, W), xm) if return_maps else None
     _lib.call("stabnet_warp_rev_bundle2", ptr(img), ptr(xm), ptr(ym), N, H, W, C, rate, ptr(out), ptr(ws), ptr(px), ptr(py),
-              stream_ptr())
+              stream_ptr(img.device), device=img.device)
     if squeeze:
         out = out[0]
     return (out, px, py) if return_maps else out
@@ -118,7 +126,8 @@ def black_accumulate(black: torch.Tensor, all_black: torch.Tensor):
     """all_black (int32, same numel) += round(black)   (deploy_bundle.py:291)."""
     black = dev_f32(black, "black")
     assert all_black.dtype == torch.int32 and all_black.is_cuda and all_black.numel() == black.numel()
-    _lib.call("stabnet_black_accumulate", ptr(black), ptr(all_black), black.numel(), stream_ptr())
+    _lib.call("stabnet_black_accumulate", ptr(black), ptr(all_black), black.numel(), stream_ptr(black.device),
+              device=black.device)
     return all_black
 
 
@@ -131,6 +140,7 @@ def max_inscribed_rect(all_black: torch.Tensor, step: int = 10):
     nbytes = _lib.lib().stabnet_crop_search_workspace_bytes(H, W, step)
     ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=all_black.device)
     ans = torch.empty(5, dtype=torch.int32, device=all_black.device)
-    _lib.call("stabnet_crop_search", ptr(all_black), H, W, step, ptr(ans), ptr(ws), ws.numel() * 8, stream_ptr())
+    _lib.call("stabnet_crop_search", ptr(all_black), H, W, step, ptr(ans), ptr(ws), ws.numel() * 8,
+              stream_ptr(all_black.device), device=all_black.device)
     a = ans.cpu().tolist()
     return (a[:4], a[4]) if a[4] > 0 else ([], 0)

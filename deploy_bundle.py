@@ -8,8 +8,8 @@ which the reference does in NumPy on the host.  Differences forced by the offlin
     stabnet_amd/tf_checkpoint.py without TensorFlow; the `.meta` graph is not needed) or a `.npz` written by
     train_bundle_nobm.py (TF variable names); without one, seeded synthetic weights are used and said so.
   * OpenCV is absent: clips are `.npy` arrays ([T,H,W] grey in [0,255] or [T,H,W,3] BGR) under
-    <prefix>/unstable/<name>; results are written as `.npy` (stabilised grey frames, x/y maps, black masks).  With
-    cv2 importable, video files are read and an MJPG .avi is written like the reference does.
+    <prefix>/unstable/<name>; results are written as `.npy` (stabilised grey frames, x/y maps, black masks).  Video
+    decode / MJPG encode (cv2.VideoCapture / VideoWriter in the reference) are outside the path and not implemented.
   * --before-ch is parsed and ignored exactly as in the reference (deploy_bundle.py:15,41): the ring depth is
     max(indices[1:]) = 32 and six frames are sampled at lags 1,2,4,8,16,32.
 """
@@ -101,12 +101,21 @@ def main():
     print('inference with {}'.format(list(lags)))
     if args.before_ch is not None and args.before_ch != max(lags):
         print('note: --before-ch %d is ignored (as in the reference); ring depth = %d' % (args.before_ch, max(lags)))
-    if args.max_span != 1 or args.random_black is not None or args.no_bm == 0 or args.infer_with_last:
-        print('note: --max-span/--random-black/--no_bm=0/--infer-with-last are debugging paths of the reference that '
-              'are not on the timed path; they are accepted and ignored')
+    ignored = [flag for flag, on in (('--max-span', args.max_span != 1), ('--random-black', args.random_black is not None),
+                                     ('--no_bm=0', args.no_bm == 0), ('--infer-with-last', args.infer_with_last),
+                                     ('--infer-with-stable', args.infer_with_stable),
+                                     ('--start-with-stable', args.start_with_stable), ('--deploy-vis', args.deploy_vis)) if on]
+    if ignored:
+        # --infer-with-stable / --start-with-stable / --deploy-vis read the ground-truth STABLE video (deploy_bundle.py:73,
+        # 88-89,237-246,319-320): debugging aids that need the paired clip; with --infer-with-stable the reference also stops
+        # appending to before_masks while still popping it (:319-328), i.e. it only runs for 32 frames.
+        print('note: %s: debugging paths of the reference that are not on the timed path; accepted and ignored'
+              % '/'.join(ignored))
     params = load_weights(args, cfg)
-    stream = StabNetStream(params, H, W, cfg, streams=1, device=args.device, refine=args.refine, before_ch=args.before_ch)
     dev = torch.device(args.device)
+    torch.cuda.set_device(dev)
+    stream = StabNetStream(params, H, W, cfg, streams=1, device=dev, refine=args.refine, before_ch=args.before_ch)
+    stream.track_black()            # all_black += round(black) inside every refine pass (deploy_bundle.py:234,291), on the device
 
     clips = []
     if args.synthetic > 0:
@@ -132,7 +141,6 @@ def main():
         print(name)
         tot_time, length = 0.0, 0
         frames_out, xmaps, ymaps, blacks, colour_out = [], [], [], [], []
-        all_black = torch.zeros((H, W), dtype=torch.int32, device=dev)           # deploy_bundle.py:234,291
         try:
             first = grey_train(clip[0], H, W)
             stream.start(torch.from_numpy(first[None]).to(dev))                       # ring = 32 x first frame, zero masks
@@ -143,7 +151,6 @@ def main():
                 r = stream.step(cur)                                                  # one sess.run-equivalent
                 torch.cuda.synchronize()
                 tot_time += time.time() - start
-                warp.black_accumulate(r['black_pix'][0], all_black)
                 if np.asarray(clip[t]).ndim == 3 and np.asarray(clip[t]).shape[:2] == (H, W):
                     # warpRevBundle2 (deploy_bundle.py:136-146,303) on the device: colour frame remapped by the smoothed maps
                     bgr = torch.from_numpy(np.ascontiguousarray(clip[t], dtype=np.uint8)).to(dev)
@@ -168,7 +175,7 @@ def main():
                 np.savez_compressed(stem + '_maps.npz', x_map=np.stack(xmaps), y_map=np.stack(ymaps), black=np.stack(blacks))
                 print('wrote', stem + '_stable.npy')
                 # max-inscribed black-free rectangle over the whole clip (deploy_bundle.py:344-371), searched on the device
-                ans, area = warp.max_inscribed_rect(all_black)
+                ans, area = warp.max_inscribed_rect(stream.all_black[0])
                 if ans:
                     src = np.stack(colour_out) if colour_out else np.stack(frames_out)
                     np.save(stem + '_cut.npy', src[:, ans[0]:ans[2] + 1, ans[1]:ans[3] + 1])

@@ -32,9 +32,10 @@ int stabnet_abi_version(void);
 /* get_4_pts(theta, batch_size) -> pts2            s_net_bundle_nobm.py:29-71
  * + get_Hs(pts2) -> Hs                           spatial_transformer3.py:179-198 (get_H/pinv :144-175)
  * theta [N,(gh+1)(gw+1)*2] -> pts2 [N,gh+1,gw+1,2] (vertex = regular grid + offset, clipped to +-1/do_crop_rate),
- * Hs [N,gh,gw,9] (h = inv(A + 1e-4 I) b, last entry 1).  pts1 is a re-packing of pts2 done by the host mirror. */
+ * Hs [N,gh,gw,9] (h = inv(A + 1e-4 I) b, last entry 1), pts1 [N,gh,gw,8] (optional, may be NULL): per cell
+ * [x_TL,x_TR,x_BL,x_BR,y_TL,y_TR,y_BL,y_BR] (s_net_bundle_nobm.py:65-66). */
 int stabnet_get_4_pts(const float* theta, int N, int grid_h, int grid_w, float do_crop_rate,
-                      float* pts2, float* Hs, void* stream);
+                      float* pts1, float* pts2, float* Hs, void* stream);
 
 /* transformer(U, theta=pts2) -> (output, black_pix, img=[x_map,y_map])   spatial_transformer3.py:19,218-301,362-365
  * Fetched in deploy as output_img:0, black_pix:0, get_Hs/Hs:0, x_map:0, y_map:0 (deploy_bundle.py:48-56,286).
@@ -132,15 +133,18 @@ int stabnet_ring_init(float* frames_ring, float* masks_ring, const float* first_
  * the feedback after it:  13-channel stack from the ring at the dilated `lags` (HOST int array, e.g. 1,2,4,8,16,32;
  * channel order masks, frames, current) -> regressor -> get_4_pts -> transformer -> frame = img - black ->
  * frames_ring[head] = frame, masks_ring[head] = black.  refine > 1 repeats the network on the refined frame
- * (:284-295).  `head` is a DEVICE int (ring slot of this frame's push); the call advances it to (head+1) % depth with
- * a one-thread kernel, so every argument is fixed across frames and the call can be captured into a hipGraph once and
- * replayed (copy the new frame into the fixed `cur_frame` buffer before each replay).
+ * (:284-295).  `head` is a DEVICE int[2] = {ring slot of this frame's push, ticket counter (zero it once)}; the call
+ * advances head[0] to (head+1) % depth on the device (by the last block of the sampler when refine = 1 -- sampler,
+ * feedback push and advance are one launch -- else by a one-thread kernel), so every argument is fixed across frames
+ * and the call can be captured into a hipGraph once and replayed (copy the new frame into the fixed `cur_frame` buffer
+ * before each replay).  all_black (optional, may be NULL): int32 [S,H,W] += round(black) once per refine pass
+ * (deploy_bundle.py:291, inside the refine loop) -- the input of stabnet_crop_search.
  * Outputs: theta [S,n_theta]; out_img, black, x_map, y_map, frame_fb [S,H,W]; Hs [S,gh,gw,9]. */
 int stabnet_deploy_frame(const void* net, const float* params, const float* fold, float* frames_ring,
                          float* masks_ring, int depth, int* head, const int* lags, int n_lags, const float* cur_frame,
                          int refine, int grid_h, int grid_w, float do_crop_rate, float* theta, float* out_img,
-                         float* black, float* x_map, float* y_map, float* Hs, float* frame_fb, void* workspace,
-                         size_t workspace_bytes, void* stream, void* prof);
+                         float* black, float* x_map, float* y_map, float* Hs, float* frame_fb, int* all_black,
+                         void* workspace, size_t workspace_bytes, void* stream, void* prof);
 
 /* ---- optional per-launch timing (bench.py roofline leg) --------------------------------------------------
  * A profiler handle owns HIP events (host objects).  Passing it as `prof` to a forward makes that call record an
@@ -158,15 +162,25 @@ const char* stabnet_prof_kind_name(int kind);
  * These replace what TF autodiff generates for `opt.minimize(total_loss)` (train_bundle_nobm.py:160) over the ops
  * above.  floor / casts / comparisons carry no gradient (corners, black_pix, z sign, warp_pts indices are constants). */
 
-/* d transformer / d pts2 (pre-clip vertex gradient) [N,gh+1,gw+1,2] from d_out [N,H,W,C], d_xmap, d_ymap [N,H,W]
- * (each may be NULL).  x_map, y_map, Hs: the forward's outputs.  workspace: N*gh*gw*8 doubles (8-B aligned). */
+/* Reproducibility: every reduction below is order-independent (64-bit fixed-point accumulation, scale 2^40, or block
+ * partials added in a fixed order) -- two runs of a training step on the same inputs give the same bits.
+ *
+ * d transformer / d pts2 (pre-clip vertex gradient) [N,gh+1,gw+1,2] from d_out [N,H,W,C], d_xmap, d_ymap [N,H,W]
+ * (each may be NULL); dmap_scale [N] (optional) multiplies d_xmap / d_ymap per sample (stabnet_feature_loss hands over
+ * signed counts and that factor).  x_map, y_map, Hs: the forward's outputs.  workspace: N*gh*gw*8 8-byte words (8-B aligned). */
 int stabnet_transformer_bwd(const float* pts2, const float* Hs, const float* U, const float* x_map, const float* y_map,
-                            const float* d_out, const float* d_xmap, const float* d_ymap, int N, int H, int W, int C,
-                            int grid_h, int grid_w, float* d_pts2, void* workspace, void* stream);
+                            const float* d_out, const float* d_xmap, const float* d_ymap, const float* dmap_scale, int N,
+                            int H, int W, int C, int grid_h, int grid_w, float* d_pts2, void* workspace, void* stream);
 
-/* d interpolate(im, x, y) / d im  (train_bundle_nobm.py:117-118): scatter-add of the four taps; d_im is zeroed first unless accumulate. */
+/* d interpolate(im, x, y) / d im  (train_bundle_nobm.py:117-118): scatter-add of the four taps, d_im (+)= it.
+ * workspace: N*H*W*C 8-byte words (8-B aligned). */
 int stabnet_interp_bwd(const float* x, const float* y, const float* d_out, int N, int H, int W, int C, float* d_im,
-                       int accumulate, void* stream);
+                       int accumulate, void* workspace, void* stream);
+
+/* Re-packing helpers of the host mirror: out [npix] = x[npix][C][:, c] (x_tensor[..., 12:13] of s_net_bundle_nobm.py:281,
+ * flow[..., 0]); out [n][2] = (a, b) interleaved (img = [x_map, y_map], spatial_transformer3.py:295). */
+int stabnet_slice_channel(const float* x, long npix, int C, int c, float* out, void* stream);
+int stabnet_interleave2(const float* a, const float* b, long n, float* out, void* stream);
 
 /* y = a*x + b elementwise (1 - black_pix of train_bundle_nobm.py:118). */
 int stabnet_axpb(const float* x, float a, float b, long n, float* y, void* stream);
@@ -174,21 +188,23 @@ int stabnet_axpb(const float* x, float a, float b, long n, float* y, void* strea
 /* masked MSE of img_loss (s_net_bundle_nobm.py:347-352, m2 = NULL) and temp_loss (train_bundle_nobm.py:110-125,
  * m2 = interp(1 - black2)): sums [N,2] = {sum((a-b)m)^2, sum m}, m = (1 - black) * m2;
  * loss = sum_n sums[n][0] / (sums[n][1] + 1e-8) / batch_size.  _grad: ga (+)= coef * dloss_unnormalised/da, gb = -that. */
+size_t stabnet_masked_mse_workspace_bytes(int N);
 int stabnet_masked_mse_sums(const float* a, const float* b, const float* black, const float* m2, int N, long hw,
-                            float* sums, void* stream);
+                            float* sums, void* workspace, void* stream);
 int stabnet_masked_mse_grad(const float* a, const float* b, const float* black, const float* m2, const float* sums,
                             float coef, int N, long hw, float* ga, int accumulate_a, float* gb, void* stream);
 
 /* feature loss (s_net_bundle_nobm.py:215-230,335-343): value [N] = masked mean L1 between the maps gathered at the
- * rounded stable point and the unstable point; gradient (coefficient gcoef) scattered into d_xmap, d_ymap (zeroed here;
- * both NULL = forward only); warped [N,max_matches,2] optional (ret['stable_warpped']). */
+ * rounded stable point and the unstable point; its gradient wrt the maps = d_xmap / d_ymap (signed counts +-mask scattered
+ * at the rounded pixels; zeroed here; both NULL = forward only) times dscale [N] = gcoef / max(sum mask, 1);
+ * warped [N,max_matches,2] optional (ret['stable_warpped']). */
 int stabnet_feature_loss(const float* matches, const float* mask, const float* x_map, const float* y_map, int N, int H,
-                         int W, int max_matches, float gcoef, float* value, float* d_xmap, float* d_ymap,
+                         int W, int max_matches, float gcoef, float* value, float* d_xmap, float* d_ymap, float* dscale,
                          float* warped, void* stream);
 
 /* losses4 = {id2_loss (= mean|theta| * id_mul, :263), black_pos mean (:139-146,312-317), distortion (:148-181),
  * consistency (:183-210)}; d_theta [N,n_theta] = clip-mask (:58) * (d_pts2_warp + w_dist d dist + w_cons d cons +
- * w_black d black) + w_id * d id2_loss. */
+ * w_black d black) + w_id * d id2_loss (d_theta may be NULL: values only). */
 int stabnet_mesh_losses(const float* theta, const float* d_pts2_warp, int N, int grid_h, int grid_w, float do_crop_rate,
                         float id_mul, float w_id, float w_dist, float w_cons, float use_black, float w_black,
                         float* losses4, float* d_theta, void* stream);
@@ -196,9 +212,12 @@ int stabnet_mesh_losses(const float* theta, const float* d_pts2_warp, int N, int
 /* ---- training: convolution backward (autodiff of slim conv2d) --------------------------------------------- */
 
 /* dW (OHWI, ACCUMULATED into, not zeroed) += d conv2d / d weights.  x: forward input; (in_scale,in_shift): the forward's
- * folded-BN + ReLU prologue (both or NULL); dy [N,Ho,Wo,Cout].  Exact float32 MFMA, float atomics across pixel splits. */
+ * folded-BN + ReLU prologue (both or NULL); dy [N,Ho,Wo,Cout].  Exact float32 MFMA; the pixel range is split over
+ * workgroups whose partial tiles go to slabs in `workspace` and are added in split order (reproducible, no atomics). */
+size_t stabnet_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int stabnet_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* in_scale, const float* in_shift,
-                         int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
+                         int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* dx [N,H,W,Cin] = d conv2d / d input (+ residual if given, may alias dx) from dy [N,Ho,Wo,Cout] and the forward
  * weights (OHWI).  Cout % 16 == 0.  workspace: stabnet_conv2d_dgrad_workspace_bytes() (re-packed weights + split-K). */
@@ -221,14 +240,24 @@ int stabnet_tower_fwd_train(const void* net, float* params, const float* x_tenso
  * params; zero once per step). */
 int stabnet_tower_bwd(const void* net, const float* params, const float* d_theta, float* grads, void* workspace,
                       size_t workspace_bytes, void* stream, void* prof);
+/* The same backward in stabnet_net_num_grad_stages() stages (0: FC head + block4, 1: block3, 2: block2, 3: block1 + stem;
+ * call them in this order).  When stage k's kernels are done the gradients in [lo, hi) of stabnet_net_grad_bucket(k) are
+ * final for this tower -- a data-parallel host hands that bucket to the collective while the earlier layers are still in
+ * backward (reverse layer order).  The BN gamma / beta sections (stabnet_net_bn_grad_range) are final after the last stage. */
+int stabnet_tower_bwd_stage(const void* net, const float* params, const float* d_theta, float* grads, void* workspace,
+                            size_t workspace_bytes, int stage, void* stream, void* prof);
+int stabnet_net_num_grad_stages(void);
+int stabnet_net_grad_bucket(const void* net, int stage, long* lo, long* hi);
+int stabnet_net_bn_grad_range(const void* net, long* lo, long* hi);
 
 /* Float offsets, inside a tower workspace, of the batch BN buffers [G] (scale, shift, mean, invstd) of the last forward. */
 int stabnet_net_train_bn_offsets(const void* net, long* scale_off, long* shift_off, long* mean_off, long* invstd_off);
 
 /* slim L2 regularisers (REGULARIZATION_LOSSES, s_net_bundle_nobm.py:324-325; resnet.py:35-37): *loss_out +=
- * sum_seg coef*0.5*sum w^2 (NULL to skip), grads[seg] += gscale*coef*w (NULL to skip).  seg_* are DEVICE arrays. */
+ * sum_seg coef*0.5*sum w^2 (NULL to skip), grads[seg] += gscale*coef*w (NULL to skip).  seg_* are DEVICE arrays.
+ * workspace: 64*nseg floats (block partials of the value; may be NULL when loss_out is). */
 int stabnet_weight_decay(const float* params, float* grads, const long* seg_off, const long* seg_len,
-                         const float* seg_coef, int nseg, float gscale, float* loss_out, void* stream);
+                         const float* seg_coef, int nseg, float gscale, float* loss_out, float* workspace, void* stream);
 
 /* tf.train.AdamOptimizer step (train_bundle_nobm.py:155-160): g = (grads + grads2) * gscale (grads2 may be NULL). */
 int stabnet_adam_step(float* params, const float* grads, const float* grads2, float* m, float* v, long n, float lr,

@@ -570,6 +570,44 @@ def regu_loss(p, cfg: Config):
     return F(tot)
 
 
+# --------------------------------------------------------------------------- optimiser (SURVEY 8a row a20)
+def exponential_decay_staircase(lr0, global_step, decay_steps, decay_rate):
+    """[external] tf.train.exponential_decay(..., staircase=True) as called at train_bundle_nobm.py:155-158:
+    float32 `lr0 * pow(decay_rate, floor(global_step / decay_steps))`."""
+    p = F(np.floor(F(global_step) / F(decay_steps)))
+    return F(F(lr0) * F(np.power(F(decay_rate), p)))
+
+
+class AdamTF:
+    """[external] tf.train.AdamOptimizer (TF 1.3) as used at train_bundle_nobm.py:159-160, defaults beta1 0.9,
+    beta2 0.999, epsilon 1e-8.  Restated from the published ApplyAdam CPU kernel (training_ops.cc, Eigen expressions,
+    one rounding per op, no FMA):
+        alpha = lr * sqrt(1 - beta2_power) / (1 - beta1_power)
+        m += (g - m) * (1 - beta1);  v += (g*g - v) * (1 - beta2);  var -= (m * alpha) / (sqrt(v) + epsilon)
+    beta1_power / beta2_power are float32 variables initialised to beta1 / beta2 and multiplied by beta after every
+    step (AdamOptimizer._finish).  dtype float32 reproduces TF's arithmetic; float64 is the exact-arithmetic shadow."""
+
+    def __init__(self, n, beta1=0.9, beta2=0.999, epsilon=1e-8, dtype=np.float32):
+        self.T = dtype
+        self.beta1, self.beta2, self.eps = dtype(beta1), dtype(beta2), dtype(epsilon)
+        self.m = np.zeros(n, dtype)
+        self.v = np.zeros(n, dtype)
+        self.b1p, self.b2p = dtype(beta1), dtype(beta2)
+
+    def step(self, var, grad, lr):
+        T = self.T
+        var = np.asarray(var, T)
+        g = np.asarray(grad, T)
+        one = T(1)
+        alpha = T(T(lr) * np.sqrt(one - self.b2p, dtype=T) / (one - self.b1p))
+        self.m = (self.m + (g - self.m) * (one - self.beta1)).astype(T)
+        self.v = (self.v + (g * g - self.v) * (one - self.beta2)).astype(T)
+        var = (var - (self.m * alpha) / (np.sqrt(self.v, dtype=T) + self.eps)).astype(T)
+        self.b1p = T(self.b1p * self.beta1)
+        self.b2p = T(self.b2p * self.beta2)
+        return var
+
+
 # --------------------------------------------------------------------------- tower
 def inference_stable_net(x_tensor, p, cfg: Config, y=None, matches=None, mask=None,
                          use_black_loss=1.0, use_theta_only=0.0, training=False):

@@ -1,0 +1,167 @@
+"""GPU parity AT THE BASELINE.json SIZES:
+  configs[0]  256x256 clip, 64 frames, seed 1234    -> StabNetStream vs the committed oracle trajectory + per-frame checksums
+  configs[1]  1280x720, batch 1                     -> one deploy_step (ring -> regressor -> warp -> feedback) vs the oracle
+  configs[2]  training, 8 pairs at 288x512          -> forward losses vs the NumPy oracle (training=True) and the full-step
+                                                       gradient of every parameter tensor vs float64 autograd
+(configs[3] needs 8 GPUs; configs[4] = test_fullsize_gpu.py::test_stream_at_1080p_*.)"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stabnet_oracle as O
+from oracle import torch_ref as T
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip_256x256_t64.npz")
+
+
+def _lipschitz_pixel_check(src, got_out, ref, got_xm, got_ym, H, W):
+    """Warped pixels: bilinear sampling is Lipschitz in the sample position (<= 2G per pixel of displacement, G = largest
+    neighbour difference of the source), so the map tolerance bounds the pixel error -- except where the sample sits on
+    the frame border, where the reference's clipped-corner weights make the sampler discontinuous."""
+    G = max(np.abs(np.diff(src, axis=0)).max(), np.abs(np.diff(src, axis=1)).max())
+    dpx = np.abs(got_xm - ref["x_map"]) * W / 2 + np.abs(got_ym - ref["y_map"]) * H / 2
+    bound = 2 * G * dpx[0, :, :, 0] + 1e-5
+    xp = (ref["x_map"][0, :, :, 0] + 1) * W / 2
+    yp = (ref["y_map"][0, :, :, 0] + 1) * H / 2
+    tol = 0.05
+    border = (np.abs(xp) < tol) | (np.abs(xp - (W - 1)) < tol) | (np.abs(yp) < tol) | (np.abs(yp - (H - 1)) < tol)
+    err = np.abs(got_out - ref["output"])[0, :, :, 0]
+    assert (err <= bound)[~border].all(), "max excess %g" % float((err - bound)[~border].max())
+
+
+def test_deploy_step_720p_matches_oracle(cuda):
+    """configs[1]: the timed call of deploy_bundle.py:286 at 1280x720, through the on-device ring."""
+    from stabnet_amd import synthetic, warp
+    from stabnet_amd.config import Config
+    from stabnet_amd.deploy import StabNetStream
+    H, W = 720, 1280
+    cfg, ocfg = Config(height=H, width=W), O.Config(height=H, width=W)
+    P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
+    clip = synthetic.make_clip(H, W, 3, seed=1234)
+    s = StabNetStream(P, H, W, cfg, streams=1, device=cuda)
+    s.start(torch.from_numpy(clip[0:1]).to(cuda))
+    ring = O.DeployRing(clip[0], ocfg)
+    for t in (1, 2):                                        # frame 2 sees frame 1's fed-back output at lag 1
+        got = s.step(torch.from_numpy(clip[t:t + 1]).to(cuda))
+        torch.cuda.synchronize()
+        ref, frame = O.deploy_step(ring, clip[t], P, ocfg)
+        th = got["theta"].cpu().numpy()
+        assert np.abs(th - ref["theta"]).max() <= 2e-5, (t, float(np.abs(th - ref["theta"]).max()))
+        xm, ym = got["x_map"].cpu().numpy(), got["y_map"].cpu().numpy()
+        assert np.abs(xm - ref["x_map"]).max() < 1e-4 and np.abs(ym - ref["y_map"]).max() < 1e-4, t
+        flips = got["black_pix"].cpu().numpy() != ref["black_pix"]
+        edge = (np.abs(np.abs(ref["x_map"][..., 0]) - 1) < 1e-4) | (np.abs(np.abs(ref["y_map"][..., 0]) - 1) < 1e-4)
+        assert not (flips & ~edge).any(), t
+        _lipschitz_pixel_check(clip[t], got["output"].cpu().numpy(), ref, xm, ym, H, W)
+        # given the oracle's theta everything downstream is bit-exact at 720p too
+        cur = torch.from_numpy(clip[t]).to(cuda).reshape(1, H, W, 1)
+        r2 = warp.warp_from_theta(cur, torch.from_numpy(ref["theta"]).to(cuda), cfg)
+        assert np.array_equal(r2["output"].cpu().numpy(), ref["output"]), t
+        assert np.array_equal(r2["black_pix"].cpu().numpy(), ref["black_pix"]), t
+        assert np.array_equal(r2["Hs"].cpu().numpy(), ref["Hs"]), t
+        # the fed-back frame the recurrence carries forward
+        d = np.abs(got["frame"].cpu().numpy()[0] - frame)
+        assert np.quantile(d, 0.999) < 5e-3, (t, float(d.max()))
+
+
+def test_config1_clip_256_stream_vs_golden(cuda):
+    """configs[0]: the 64-frame 256x256 clip through StabNetStream (graph replay on), against the oracle trajectory
+    committed by oracle/make_golden_clip.py.  Two layers of checking per frame:
+      (1) free-running: theta / strided map + pixel samples / sums of the fed-back loop stay within the stated tolerance
+          of the oracle's over all 63 steps (the recurrence does not amplify the float32 summation-order differences);
+      (2) teacher-forced: with the golden theta of that frame, the GPU warp reproduces the golden CRC32 of x_map, y_map,
+          black and out -- the per-frame checksums of SURVEY 8d Config 1, bit for bit."""
+    from stabnet_amd import synthetic, warp
+    from stabnet_amd.config import Config
+    from stabnet_amd.deploy import StabNetStream
+    g = np.load(GOLDEN)
+    H, W, Tn, clip_seed, weight_seed, stride = (int(v) for v in g["meta"])
+    cfg = Config(height=H, width=W)
+    P = synthetic.make_params(cfg, seed=weight_seed, theta_scale=float(g["theta_scale"]))
+    clip = synthetic.make_clip(H, W, Tn, seed=clip_seed, margin=64)
+    dclip = torch.from_numpy(clip).to(cuda)
+    s = StabNetStream(P, H, W, cfg, streams=1, device=cuda, use_graph=True)
+    s.start(dclip[0:1])
+    sl = (slice(0, H, stride), slice(0, W, stride))
+    worst = {"theta": 0.0, "map": 0.0, "out": 0.0}
+    for t in range(1, Tn):
+        r = s.step(dclip[t:t + 1])
+        th = r["theta"].cpu().numpy()[0]
+        xm, ym = r["x_map"].cpu().numpy()[0, :, :, 0], r["y_map"].cpu().numpy()[0, :, :, 0]
+        out, bl = r["output"].cpu().numpy()[0, :, :, 0], r["black_pix"].cpu().numpy()[0]
+        worst["theta"] = max(worst["theta"], float(np.abs(th - g["theta"][t - 1]).max()))
+        worst["map"] = max(worst["map"], float(np.abs(xm[sl] - g["x_map_s"][t - 1]).max()),
+                           float(np.abs(ym[sl] - g["y_map_s"][t - 1]).max()))
+        worst["out"] = max(worst["out"], float(np.abs(out[sl] - g["out_s"][t - 1]).max()))
+        assert abs(float(bl.sum()) - g["sums"][t - 1, 2]) <= 64, t               # black pixels: edge flips only
+        assert abs(float(xm.sum(dtype=np.float64)) - g["sums"][t - 1, 0]) <= 1e-4 * H * W, t
+        # (2) teacher-forced checksums
+        r2 = warp.warp_from_theta(dclip[t].reshape(1, H, W, 1), torch.from_numpy(g["theta"][t - 1:t]).to(cuda), cfg)
+        crc = [zlib.crc32(np.ascontiguousarray(r2[k].cpu().numpy(), np.float32).tobytes())
+               for k in ("x_map", "y_map", "black_pix", "output")]
+        assert crc == [int(c) for c in g["crc"][t - 1]], (t, crc)
+    # tolerances: theta 5e-5 (63 recurrent steps; single-frame bar is 2e-5), maps 3e-4 normalised (0.04 px), samples 2e-2
+    # of the [-0.5, 0.5] range at the strided positions (Lipschitz in the map error)
+    assert worst["theta"] <= 5e-5 and worst["map"] <= 3e-4 and worst["out"] <= 2e-2, worst
+    assert s._graph is not None
+
+
+def _train_setup(N, H, W):
+    from stabnet_amd import synthetic
+    from stabnet_amd.config import Config
+    cfg = Config(height=H, width=W, batch_size=N, max_matches=512)
+    ocfg = O.Config(height=H, width=W, batch_size=N, max_matches=512)
+    P = synthetic.make_params(cfg, seed=0, theta_scale=0.3)
+    b = synthetic.make_train_batch(cfg, N, H, W, 1234)
+    b["flow"] = (b["flow"] + np.random.default_rng(1).normal(0, 0.01, b["flow"].shape)).astype(np.float32)
+    return cfg, ocfg, P, b
+
+
+def test_training_step_8x288x512_matches_oracles(cuda):
+    """configs[2]: one siamese step at 8 pairs, 288x512 (fwd + bwd incl. warp grad; Adam is test_adam_gpu.py)."""
+    from stabnet_amd.train import Trainer
+    N, H, W = 8, 288, 512
+    cfg, ocfg, P, b = _train_setup(N, H, W)
+    gates = {"use_theta_loss": 1, "use_temp_loss": 1, "use_black_loss": 1, "use_theta_only": 0}
+    tr = Trainer(P, N, H, W, cfg, device=cuda)
+    dev_b = {k: torch.from_numpy(v).to(cuda) for k, v in b.items()}
+    tr.forward_backward(dev_b, gates, apply_update=False)
+    torch.cuda.synchronize()
+    lo = tr.losses()
+    got_flat = tr.grad_flat().cpu().numpy()
+
+    # ---- forward vs the NumPy float32 oracle in training mode (batch-statistics BN), both towers + temporal loss
+    r = [O.inference_stable_net(b["x" + s], P, ocfg, y=b["y" + s], matches=b["matches" + s], mask=b["mask" + s],
+                                use_black_loss=1.0, use_theta_only=0.0, training=True) for s in ("1", "2")]
+    for k in (0, 1):
+        assert np.abs(tr.theta[k].cpu().numpy() - r[k]["theta"]).max() < 5e-5, k
+        t = lo["tower%d" % (k + 1)]
+        for key in ("img_loss", "feature_loss", "distortion_loss", "consistency_loss", "theta_loss"):
+            assert t[key] == pytest.approx(float(r[k][key]), rel=2e-3, abs=1e-7), (k, key)
+        assert t["total_loss"] == pytest.approx(float(r[k]["total_loss"]), rel=2e-3), k
+    temp = O.temporal_loss(r[0]["output"], r[0]["black_pix"], r[1]["output"], r[1]["black_pix"], b["flow"], ocfg, 1.0)
+    assert lo["temp_loss"] == pytest.approx(float(temp) * cfg.temp_mul, rel=5e-3, abs=1e-6)
+    total = float(r[0]["total_loss"]) + float(r[1]["total_loss"]) + float(temp) * cfg.temp_mul      # train_bundle_nobm.py:142
+    assert lo["total_loss"] == pytest.approx(total, rel=2e-3)
+
+    # ---- backward vs float64 autograd of the same objective, every trainable tensor
+    pt = {k: T.t(v, requires_grad=True) for k, v in P.items()}
+    tot64, _ = T.train_objective(pt, b, ocfg, 1.0, 1.0, 0.0, training=True)
+    tot64.backward()
+    assert lo["total_loss"] == pytest.approx(float(tot64), rel=2e-3)
+    want_flat = tr.plan.pack({k: (pt[k].grad.numpy() if pt[k].grad is not None else np.zeros(P[k].shape)) for k in P})[:tr.nt]
+    gmax = np.abs(want_flat).max()
+    for name, off, kind, dims, aux in tr.plan.table:
+        if kind in (4, 5):
+            continue
+        n = int(np.prod([d for d in dims if d > 0]))
+        gg, ww = got_flat[off:off + n], want_flat[off:off + n]
+        scale = max(np.abs(ww).max(), 1e-5 * gmax)
+        err = np.abs(gg - ww).max() / scale
+        assert err < 2e-2, "%s: rel err %g (scale %g)" % (name, err, scale)
+    cos = float(np.dot(got_flat, want_flat) / (np.linalg.norm(got_flat) * np.linalg.norm(want_flat)))
+    assert cos > 1 - 1e-5, cos

@@ -57,3 +57,36 @@ def test_two_rank_gradient_sum_equals_global_batch():
     (((X @ w) ** 2).sum() / 5).backward()
     for rank, g, tail in res:
         assert np.allclose(g, w.grad.numpy(), rtol=1e-12, atol=1e-12) and tail == 0.0
+
+
+def test_grad_buckets_partition_the_trainables():
+    """Host-only: the four backward stages' buckets + the BN gamma/beta range tile the gradient buffer exactly, in reverse
+    layer order (stage 0 = the END of the weight region: block4 + FC head)."""
+    import ctypes
+    from stabnet_amd import _lib
+    from stabnet_amd.config import Config
+    from stabnet_amd.regressor import NetPlan
+    plan = NetPlan(2, 64, 96, Config(height=64, width=96), keep_activations=True)
+    L = _lib.lib()
+    n = L.stabnet_net_num_grad_stages()
+    lo, hi = ctypes.c_long(), ctypes.c_long()
+    ranges = []
+    for k in range(n):
+        _lib.call("stabnet_net_grad_bucket", plan.handle, k, ctypes.byref(lo), ctypes.byref(hi))
+        ranges.append((lo.value, hi.value))
+    _lib.call("stabnet_net_bn_grad_range", plan.handle, ctypes.byref(lo), ctypes.byref(hi))
+    bn = (lo.value, hi.value)
+    assert n == 4 and ranges[-1][0] == 0 and bn[1] == plan.n_trainable
+    for k in range(n - 1):
+        assert ranges[k][0] == ranges[k + 1][1] and ranges[k][0] < ranges[k][1]        # descending, contiguous
+    assert ranges[0][1] == bn[0]
+    # stage membership by name: block4 + fc in stage 0, block3 in 1, block2 in 2, block1 + stem in 3
+    want = {"block4": 0, "fc/": 0, "block3": 1, "block2": 2, "block1": 3, "resnet_v2_50/conv1/": 3}
+    for name, off, kind, dims, aux in plan.table:
+        if kind in (2, 3, 4, 5):
+            continue
+        stage = next(k for k, (a, b) in enumerate(ranges) if a <= off < b)
+        key = next(k for k in want if k in name)
+        assert stage == want[key], (name, stage)
+    # sizes: 121.6 MB in all at the reference's shapes; the FC + block4 bucket carries most of it
+    assert abs(plan.n_trainable * 4 / 1e6 - 121.6) < 2.0 and (ranges[0][1] - ranges[0][0]) > 0.6 * plan.n_trainable

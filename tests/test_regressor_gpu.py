@@ -84,3 +84,44 @@ def test_full_frame_matches_oracle(cuda):
     r2 = warp.warp_from_theta(cur, torch.from_numpy(ref["theta"]).to(cuda), cfg)
     assert np.array_equal(r2["output"].cpu().numpy(), ref["output"])
     assert np.array_equal(r2["black_pix"].cpu().numpy(), ref["black_pix"])
+
+
+def test_odd_size_with_poisoned_workspace(cuda):
+    """45x77 (odd x odd: the stem's last 32-float row run of the last image reads past its taps into the slack row) with the
+    whole workspace pre-filled with NaN: the over-read meets zero weights, and 0 * NaN would poison theta unless the slack
+    row is zeroed by the stack assembly / border embedding (both entries are exercised)."""
+    from stabnet_amd.deploy import StabNetStream
+    from stabnet_amd.regressor import Regressor
+    N, H, W = 1, 45, 77
+    cfg, ocfg, P, x = _setup(N, H, W)
+    theta_ref, _, _ = O.get_resnet(x, P, ocfg)
+    reg = Regressor(P, N, H, W, cfg)
+    reg.workspace.view(torch.float32).fill_(float("nan"))
+    theta = reg(torch.from_numpy(x).to(cuda))
+    torch.cuda.synchronize()
+    assert torch.isfinite(theta).all()
+    assert np.abs(theta.cpu().numpy() - theta_ref).max() <= 2e-5
+    # the deploy entry (stack assembled from the ring) on the same odd size
+    s = StabNetStream(P, H, W, cfg, streams=1, device=cuda)
+    s.reg.workspace.view(torch.float32).fill_(float("nan"))
+    clip = torch.from_numpy(x[0, :, :, 12]).to(cuda)[None]
+    s.start(clip)
+    r = s.step(clip)
+    torch.cuda.synchronize()
+    assert torch.isfinite(r["theta"]).all() and torch.isfinite(r["output"]).all()
+
+
+def test_wrong_pointer_is_an_error_not_a_fault(cuda):
+    """The C entry points check that the buffers belong to the current device (a host pointer, or memory of another GPU
+    with the wrong device current, must come back as an error code instead of faulting inside a kernel)."""
+    from stabnet_amd import _lib
+    from stabnet_amd.regressor import Regressor
+    N, H, W = 1, 64, 96
+    cfg, ocfg, P, x = _setup(N, H, W)
+    reg = Regressor(P, N, H, W, cfg)
+    host_params = reg.params.cpu()                              # pageable host memory: not a device pointer
+    theta = torch.empty((N, cfg.n_theta), device=cuda)
+    xt = torch.from_numpy(x).to(cuda)
+    with pytest.raises(_lib.StabnetError, match="device"):
+        _lib.call("stabnet_backbone_fwd_infer", reg.plan.handle, host_params.data_ptr(), reg.fold.data_ptr(), xt.data_ptr(),
+                  theta.data_ptr(), reg.workspace.data_ptr(), reg.workspace.numel(), torch.cuda.current_stream().cuda_stream, 0)

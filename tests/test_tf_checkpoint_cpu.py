@@ -69,3 +69,30 @@ def test_checkpoint_feeds_the_plan_layout(tmp_path):
     params, extras = C.load_stabnet_variables(prefix)
     assert not extras and set(params) == set(small)
     assert all(np.array_equal(params[k], small[k]) for k in small)
+
+
+def test_imagenet_init_formats(tmp_path):
+    """The reference warm-starts from `data_video/resnet_v2_50.ckpt` (train_bundle_nobm.py:184), which slim ships as a V1
+    single-file checkpoint: a bare table file without `.index`.  That must not crash the training driver."""
+    rng = np.random.default_rng(1)
+    var = {"resnet_v2_50/block1/unit_1/bottleneck_v2/conv1/weights": rng.standard_normal((1, 1, 64, 64)).astype(np.float32),
+           "resnet_v2_50/conv1/weights": rng.standard_normal((7, 7, 3, 64)).astype(np.float32),
+           "resnet_v2_50/logits/weights": rng.standard_normal((1, 1, 2048, 1001)).astype(np.float32)}
+    v2 = str(tmp_path / "v2" / "resnet_v2_50.ckpt")
+    os.makedirs(os.path.dirname(v2))
+    C.write_bundle(v2, var)
+    assert C.checkpoint_format(v2) == "v2"
+    got, note = C.try_load_imagenet_resnet(v2)
+    assert set(got) == {"resnet_v2_50/block1/unit_1/bottleneck_v2/conv1/weights"} and "V2" in note   # conv1 + logits excluded
+    # a V1 file = the table itself under the bare name (same leveldb table magic, no .index / .data shards)
+    v1 = str(tmp_path / "v1" / "resnet_v2_50.ckpt")
+    os.makedirs(os.path.dirname(v1))
+    os.replace(v2 + ".index", v1)
+    assert C.checkpoint_format(v1) == "v1"
+    got, note = C.try_load_imagenet_resnet(v1)
+    assert got is None and "V1" in note and "seeded" in note
+    junk = str(tmp_path / "junk.ckpt")
+    open(junk, "wb").write(b"not a checkpoint" * 10)
+    assert C.checkpoint_format(junk) == "unknown" and C.try_load_imagenet_resnet(junk)[0] is None
+    assert C.checkpoint_format(str(tmp_path / "absent")) == "none"
+    assert "not found" in C.try_load_imagenet_resnet(str(tmp_path / "absent"))[1]

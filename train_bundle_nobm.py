@@ -67,17 +67,15 @@ def main():
     pg = parallel.init_process_group(device=dev)
     N, H, W = cfg.batch_size, cfg.height, cfg.width
     init = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
-    ck_prefix = args.imagenet_ckpt
-    if os.path.exists(ck_prefix + '.index') or os.path.exists(ck_prefix):
-        from stabnet_amd import tf_checkpoint
-        pre = tf_checkpoint.load_imagenet_resnet(ck_prefix)
+    from stabnet_amd import tf_checkpoint
+    pre, note = tf_checkpoint.try_load_imagenet_resnet(args.imagenet_ckpt)       # train_bundle_nobm.py:184-191,208
+    if pre is not None:
         hit = [k for k in pre if k in init and pre[k].shape == init[k].shape]
         for k in hit:
             init[k] = pre[k]
-        if rank == 0:
-            print('initialised %d backbone variables from %s' % (len(hit), ck_prefix))
-    elif rank == 0:
-        print('note: %s not found; the backbone starts from the seeded initialiser' % ck_prefix)
+        note = 'initialised %d backbone variables from %s' % (len(hit), args.imagenet_ckpt)
+    if rank == 0:
+        print('note: ' + note)
     tr = Trainer(init, N, H, W, cfg, device=dev, process_group=pg, world_size=world)
     if args.restore:
         ck = latest_checkpoint(model_dir)
@@ -118,6 +116,8 @@ def main():
             print('Iteration: ' + str(i) + ' Loss: ' + str(lo['total_loss']))
             print({k: round(float(v), 6) for k, v in lo.items() if not isinstance(v, dict)})
             print(learning_rate(i, cfg))
+        if (i % cfg.save_freq == 0 or i == training_iter - 1) and i > st_step:
+            tr.sync_moving_stats()        # (collective: every rank) BN moving statistics are per-rank (local BN); checkpoint their mean
         if (i % cfg.save_freq == 0 or i == training_iter - 1) and rank == 0 and i > st_step:
             os.makedirs(model_dir, exist_ok=True)
             sd = tr.state_dict()
