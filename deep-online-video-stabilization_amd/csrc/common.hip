@@ -23,6 +23,10 @@ int sn_check_device(const void* p, const char* what, hipStream_t st) {
         stabnet_set_error("%s is not a device pointer known to the HIP runtime", what);
         return STABNET_ERR_BAD_ARG;
     }
+    if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged) {
+        stabnet_set_error("%s is host memory (type %d), not device memory: the HIP path has no host fallback", what, (int)attr.type);
+        return STABNET_ERR_BAD_ARG;
+    }
     if (attr.type == hipMemoryTypeDevice && attr.device != cur) {
         stabnet_set_error("%s lives on device %d but device %d is current: call under torch.cuda.device(%d) / hipSetDevice",
                           what, attr.device, cur, attr.device);

@@ -73,8 +73,9 @@ def test_adam_two_gradient_buffers_and_scale(cuda):
     want = a.step(w0, ((g1 + g2) * np.float32(0.5)).astype(np.float32), 2e-5)
     w = torch.from_numpy(w0.copy()).to(cuda)
     m = torch.zeros(n, device=cuda); v = torch.zeros(n, device=cuda)
-    _lib.call("stabnet_adam_step", w.data_ptr(), torch.from_numpy(g1).to(cuda).data_ptr(), torch.from_numpy(g2).to(cuda).data_ptr(),
-              m.data_ptr(), v.data_ptr(), n, 2e-5, 0.9, 0.999, 1e-8, 1, 0.5, torch.cuda.current_stream().cuda_stream)
+    d1, d2 = torch.from_numpy(g1).to(cuda), torch.from_numpy(g2).to(cuda)       # (kept alive across the call)
+    _lib.call("stabnet_adam_step", w.data_ptr(), d1.data_ptr(), d2.data_ptr(), m.data_ptr(), v.data_ptr(), n, 2e-5, 0.9, 0.999,
+              1e-8, 1, 0.5, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(m.cpu().numpy(), a.m)
     assert (np.abs(w.cpu().numpy() - want) <= np.spacing(np.abs(want))).all()

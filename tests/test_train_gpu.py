@@ -118,7 +118,7 @@ def test_loss_decreases_on_a_fixed_batch(cuda):
     from stabnet_amd.train import Trainer
     from stabnet_amd import synthetic
     N, H, W = 2, 64, 96
-    cfg = Config(height=H, width=W, batch_size=N, max_matches=48, initial_learning_rate=2e-4)
+    cfg = Config(height=H, width=W, batch_size=N, max_matches=48)         # the reference's learning rate, 2e-5
     P = synthetic.make_params(cfg, seed=0, theta_scale=0.3)
     b = synthetic.make_train_batch(cfg, N, H, W, 5)
     dev_b = {k: torch.from_numpy(v).to(cuda) for k, v in b.items()}
@@ -129,8 +129,10 @@ def test_loss_decreases_on_a_fixed_batch(cuda):
         tr.forward_backward(dev_b, gates)
         losses.append(tr.losses()["total_loss"])
     assert all(np.isfinite(losses))
-    # a fixed trajectory (the step is deterministic): it falls well below its start and ends low
-    assert min(losses) < 0.7 * losses[0] and float(np.median(losses[10:])) < 0.9 * losses[0], losses[::3]
+    # a fixed trajectory (the step is deterministic): strictly decreasing over the 25 steps, to about half its start
+    # (measured 15.78 -> 7.98)
+    assert all(b < a for a, b in zip(losses, losses[1:])), losses
+    assert losses[-1] < 0.55 * losses[0], losses[::3]
     # ... and a second run reproduces it exactly
     tr_b = Trainer(P, N, H, W, cfg, device=cuda)
     losses_b = []
