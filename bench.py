@@ -51,6 +51,53 @@ def parse():
     return ap.parse_args()
 
 
+def csrc_sha16():
+    """Hash of the kernel sources (csrc/*.hip, *.h): the PMC traffic file is only trusted for the build it was taken on."""
+    import hashlib
+    d = os.path.join(ROOT, "deep-online-video-stabilization_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def empirical_peaks(dev):
+    """What THIS box sustains: f32 MFMA (register-only chains) and HBM copy (1 GiB, beyond the 256 MiB Infinity Cache).
+    SURVEY 8d asks for the roofline fraction against the vendor peak and against the empirical one."""
+    from stabnet_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    out = torch.empty(2048 * 256, dtype=torch.float32, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    blocks, iters = 2048, 400
+    _lib.call("stabnet_probe_mfma_f32", out.data_ptr(), blocks, 50, st)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        _lib.call("stabnet_probe_mfma_f32", out.data_ptr(), blocks, iters, st)
+    e1.record()
+    torch.cuda.synchronize()
+    mfma = 5 * L.stabnet_probe_mfma_f32_flops(blocks, iters) / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    n = 1 << 28                                             # 1 GiB of floats
+    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    _lib.call("stabnet_probe_hbm_copy", src.data_ptr(), dst.data_ptr(), n, st)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        _lib.call("stabnet_probe_hbm_copy", src.data_ptr(), dst.data_ptr(), n, st)
+    e1.record()
+    torch.cuda.synchronize()
+    hbm = 5 * 8.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    torch.cuda.empty_cache()
+    return {"mfma_f32_tflops": mfma, "hbm_copy_gbps": hbm,
+            "how": "stabnet_probe_mfma_f32 (register-only v_mfma_f32_32x32x2_f32, 2048 WGs) / stabnet_probe_hbm_copy (1 GiB float4 "
+                   "copy, read+write bytes)"}
+
+
 def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
     """BASELINE configs[2]/[3]: one optimiser step = `train_batch` siamese pairs per GPU at 288x512, full forward +
     backward (incl. warp gradient) + Adam, gradient all-reduce over RCCL when world > 1.  Returns a dict."""
@@ -72,11 +119,28 @@ def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    if world > 1:
+        tr.comm_timing = []            # event pairs around every bucket's all-reduce on the communication stream
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.forward_backward(dev_b, gates)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    comm = None
+    if world > 1:
+        # all-reduce ms per step and the fraction of it hidden under backward.  exposed = time the
+        # compute stream had to wait for the collective after its own last kernel (event on the compute stream before the
+        # join vs the end of the last bucket on the communication stream).
+        per_step = len(tr.comm_timing) // steps
+        ar_ms = sum(a.elapsed_time(b) for a, b, _ in tr.comm_timing) / steps
+        exposed = sum(max(0.0, c.elapsed_time(tr.comm_timing[(i + 1) * per_step - 1][1]))
+                      for i, c in enumerate(tr.compute_done)) / steps
+        comm = {"allreduce_ms_per_step": ar_ms, "exposed_ms_per_step": exposed,
+                "overlap_fraction": (1.0 - exposed / ar_ms) if ar_ms > 0 else None,
+                "buckets_per_step": per_step, "bytes_per_step": sum(b for _, _, b in tr.comm_timing) // steps,
+                "order": "reverse layer order: FC+block4, block3, block2, block1+stem, BN gamma/beta",
+                "backend": dist.get_backend()}
+        tr.comm_timing = None
     if dist is not None:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -84,35 +148,53 @@ def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
         dist.barrier()
     out = {"value": steps * N * world / el, "unit": "pairs/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
            "warmup": warmup, "pairs_per_gpu": N, "global_batch": N * world, "height": H, "width": W,
-           "tower_fwd_gflop": tr.plan.flops / 1e9, "loss": tr.losses()["total_loss"] if rank == 0 else None}
-    if with_prof and rank == 0:
-        prof = Profiler(max_records=4 * (steps // 2 + 1) * 600)
+           "tower_fwd_gflop": tr.plan.flops / 1e9, "loss": tr.losses()["total_loss"] if rank == 0 else None,
+           "step_gflop_algorithmic": 6.0 * tr.plan.flops / 1e9}     # 2 towers x (fwd + dgrad + wgrad); plan.flops is per tower batch
+    if comm is not None:
+        out["comm"] = comm
+    if with_prof:
+        # the conv kernels (forward, dgrad, wgrad) record HIP-event pairs inside the library; every rank runs the same
+        # instrumented steps (the collective needs all of them), rank 0 reports
+        psteps = max(1, min(steps // 2, 3))
+        prof = Profiler(max_records=psteps * 2000, device=dev)
         prof.calibrate()
         tr.prof = prof
-        for _ in range(max(1, steps // 2)):
+        for _ in range(psteps):
             tr.forward_backward(dev_b, gates)
-        roof, table = roofline_from_records(prof.records(), max(1, steps // 2))
+        roof, table = roofline_from_records(prof.records(), psteps)
         tr.prof = None
-        out["roofline"] = roof
-        out["kernels"] = table[:6]
+        if rank == 0:
+            roof["whole_step_tflops"] = out["step_gflop_algorithmic"] / out["ms_per_step"]
+            roof["whole_step_frac"] = roof["whole_step_tflops"] / PEAK_F32_MFMA_TFLOPS
+            out["roofline"] = roof
+            out["kernels"] = table[:6]
     return out
 
 
+PMC_FILE = os.path.join("profiles", "r02_pmc_hbm_traffic_bench720p.json")
+
+
 def pmc_traffic(kernel, workload_is_default):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in
-    separate runs of this same command, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  Only valid for
-    the default 720p workload the passes were taken on; None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_bench720p.json")
-    if not workload_is_default or not os.path.exists(path):
-        return None
+    """(HBM bytes per launch of `kernel`, note) from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected
+    in separate runs of this same command, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  Only valid for the
+    default 720p workload AND for the kernel sources the passes were taken on (the file carries their hash): otherwise
+    (None, why)."""
+    path = os.path.join(ROOT, PMC_FILE)
+    if not workload_is_default:
+        return None, "PMC passes exist for the default 720p workload only"
+    if not os.path.exists(path):
+        return None, "no %s (run tools/refresh_profiles.sh on the GPU box)" % PMC_FILE
     try:
         tab = json.load(open(path))
-    except Exception:
-        return None
+    except Exception as e:
+        return None, "unreadable %s: %s" % (PMC_FILE, e)
+    stamp = tab.get("__meta__", {}).get("csrc_sha16")
+    if stamp != csrc_sha16():
+        return None, "%s was taken on kernel sources %s, this build is %s: stale, not reported" % (PMC_FILE, stamp, csrc_sha16())
     for k, v in tab.items():
         if k.replace("void ", "").split("(")[0] == kernel:
-            return v["hbm_bytes_per_launch_corrected"]
-    return None
+            return v["hbm_bytes_per_launch_corrected"], "%s (rocprofv3 --pmc, separate passes; csrc %s)" % (PMC_FILE, stamp)
+    return None, "kernel %s not in %s" % (kernel, PMC_FILE)
 
 
 def roofline_from_records(recs, steps):
@@ -145,8 +227,7 @@ def roofline_from_records(recs, steps):
     return roof, table
 
 
-def cpu_baseline(P, clip, H, W, budget_s):
-    """The oracle (NumPy restatement of the reference, 'port') timed on this box's host cores on a bounded sample."""
+def _oracle_fps(P, clip, H, W, budget_s):
     from oracle import stabnet_oracle as O
     ocfg = O.Config(height=H, width=W)
     ring = O.DeployRing(clip[0], ocfg)
@@ -156,19 +237,28 @@ def cpu_baseline(P, clip, H, W, budget_s):
         O.deploy_step(ring, clip[1 + n % (len(clip) - 1)], P, ocfg)
         n += 1
         el = time.time() - t0
-        if n >= 2 and (el >= budget_s or el / n * (n + 1) > 1.5 * budget_s):
+        if el >= budget_s or el / n * (n + 1) > 1.5 * budget_s:
             break
-        if n == 1 and el > budget_s:
-            break
-    el = time.time() - t0
+    return n, time.time() - t0
+
+
+def cpu_baseline(P, clip, H, W, budget_s):
+    """The oracle (NumPy restatement of the reference, 'port') timed on this box's host cores on a bounded sample, with all
+    the cores OpenBLAS takes and with ONE thread (BASELINE.md section 2 promises both)."""
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
         thr = max([d.get("num_threads", 1) for d in threadpool_info()] + [1])
     except Exception:
-        thr = os.cpu_count()
-    return {"value": n / el, "unit": "frames/s", "cores": thr, "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": "%d sequential %dx%d frames of the same synthetic clip through oracle.deploy_step "
-                      "(NumPy/OpenBLAS restatement; the TF1 reference cannot run offline)" % (n, W, H)}
+        threadpool_limits, thr = None, os.cpu_count()
+    n, el = _oracle_fps(P, clip, H, W, 0.6 * budget_s)
+    out = {"value": n / el, "unit": "frames/s", "cores": thr, "host_cpus": os.cpu_count(), "kind": "port",
+           "sample": "%d sequential %dx%d frames of the same synthetic clip through oracle.deploy_step "
+                     "(NumPy/OpenBLAS restatement; the TF1 reference cannot run offline)" % (n, W, H)}
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            n1, el1 = _oracle_fps(P, clip, H, W, 0.4 * budget_s)
+        out["single_thread"] = {"value": n1 / el1, "unit": "frames/s", "cores": 1, "sample": "%d frame(s), BLAS limited to 1 thread" % n1}
+    return out
 
 
 def main():
@@ -211,7 +301,7 @@ def main():
                                                2 if world == 1 else 3, t["pairs_per_gpu"], t["width"], t["height"],
                                                t["global_batch"]),
                                "global_batch": t["global_batch"], "parallelism": "dp%d" % world}}
-            for k in ("roofline", "kernels", "loss", "tower_fwd_gflop"):
+            for k in ("roofline", "kernels", "loss", "tower_fwd_gflop", "comm", "step_gflop_algorithmic"):
                 if k in t:
                     line[k] = t[k]
             print(json.dumps(line))
@@ -270,12 +360,12 @@ def main():
         roof, table = roofline_from_records(prof.records(), args.steps)
         for row in table:                      # the HBM-bound kernel of the path: the fused map + gather warp
             if row["kernel"] == "warp_sample_kernel":
-                roof_warp = {"bound": "hbm", "kernel": "warp_sample_kernel<4>", "achieved": row["gbps"], "peak": PEAK_HBM_GBPS,
+                # sampler + feedback push in one launch: 20 HW (src, out, black, maps) + 12 HW (ring frame, ring mask, frame_fb)
+                roof_warp = {"bound": "hbm", "kernel": "warp_sample_kernel<4, 1>", "achieved": row["gbps"], "peak": PEAK_HBM_GBPS,
                              "unit": "GB/s", "frac": row["gbps"] / PEAK_HBM_GBPS, "avg_launch_us": row["avg_us"],
-                             "algorithmic_bytes_per_launch": S * (20.0 * H * W + 776.0),
-                             "traffic": pmc_traffic("warp_sample_kernel<4>", (H, W, S, args.refine) == (720, 1280, 1, 1))}
-        roof["traffic"] = pmc_traffic(roof["kernel"], (H, W, S, args.refine) == (720, 1280, 1, 1))
-        roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic_bench720p.json (rocprofv3 --pmc, separate passes)"
+                             "algorithmic_bytes_per_launch": S * (32.0 * H * W + 776.0),
+                             "traffic": pmc_traffic("warp_sample_kernel<4, 1>", (H, W, S, args.refine) == (720, 1280, 1, 1))[0]}
+        roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], (H, W, S, args.refine) == (720, 1280, 1, 1))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -284,7 +374,8 @@ def main():
     if not args.no_train_leg:
         del stream
         torch.cuda.empty_cache()
-        train = train_leg(args, dev, dist, rank, world, args.train_steps, 3, False)
+        train = train_leg(args, dev, dist, rank, world, args.train_steps, 3, not args.no_roofline)
+    peaks = empirical_peaks(dev) if (rank == 0 and not args.no_roofline) else None
 
     if dist is not None:
         dist.barrier()
@@ -302,7 +393,7 @@ def main():
                                    "independent stream set per GPU (replicas only)" % (W, H, S, args.before_ch),
                        "height": H, "width": W, "streams_per_gpu": S, "refine": args.refine,
                        "backbone_gflop_per_frame": plan_flops / 1e9 / S,
-                       "launches_per_frame": plan_launches + 5, "hip_graph": bool(graph_used)},
+                       "launches_per_frame": plan_launches + 3 + 1, "hip_graph": bool(graph_used)},   # + assemble, mesh, sampler(+push), frame copy
             "per_gpu_fps": fps / world, "checksum": checksum,
             # BASELINE.json words the metric per GPU; `value` is the whole-job aggregate the bench contract asks for and
             # `per_gpu_fps` the per-GPU figure (identical at N = 1); the training half of the metric is the `train` object
@@ -315,6 +406,14 @@ def main():
             line["kernels"] = table[:8]
             line["instrumented_ms_per_step"] = prof_ms
             line["roofline"]["event_pair_overhead_us_subtracted"] = 1e3 * event_overhead_ms
+            line["roofline"]["whole_frame_tflops"] = plan_flops / (el / args.steps) / 1e12
+            line["roofline"]["whole_frame_frac"] = line["roofline"]["whole_frame_tflops"] / PEAK_F32_MFMA_TFLOPS
+        if peaks is not None:
+            line["empirical_peaks"] = peaks
+            if roof is not None and roof.get("bound") == "mfma":
+                line["roofline"]["frac_of_empirical_peak"] = roof["achieved"] / peaks["mfma_f32_tflops"]
+            if roof_warp is not None:
+                line["roofline_warp"]["frac_of_empirical_peak"] = roof_warp["achieved"] / peaks["hbm_copy_gbps"]
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if train is not None:

@@ -16,6 +16,7 @@
 #include "prof.h"
 #include "train_layers.h"
 #include <algorithm>
+#include <cstdlib>
 
 typedef float f32x16w __attribute__((ext_vector_type(16)));
 
@@ -159,8 +160,9 @@ __global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(const float* __
 
 // Split of the pixel range: ~1024 blocks in all, at least 256 pixels (8 steps) per block.
 int wgrad_splits(int Cout, int K, int M, int* rows_per_split) {
+    static const int target = []() { const char* v = getenv("STABNET_WGRAD_BLOCKS"); return v ? atoi(v) : 1024; }();   // (tuning switch)
     const int tiles = cdiv(Cout, 64) * cdiv(K, 64);
-    int splits = std::max(1, std::min(cdiv(1024, tiles), cdiv(M, 256)));
+    int splits = std::max(1, std::min(cdiv(target, tiles), cdiv(M, 256)));
     splits = std::min(splits, 65535);
     const int rps = cdiv(cdiv(M, splits), 32) * 32;
     if (rows_per_split) *rows_per_split = rps;
@@ -185,7 +187,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ g
     const long i = (q - t.prefix[lo]) * 4;
     const float* s = slabs + e.slab_off + i;
     float4 acc = *reinterpret_cast<const float4*>(s);
-    for (int z = 1; z < e.splits; ++z) {
+    int z = 1;
+    for (; z + 3 < e.splits; z += 4) {                          // four slab loads in flight, added in slab order
+        const float4 v0 = *reinterpret_cast<const float4*>(s + (size_t)z * e.elems);
+        const float4 v1 = *reinterpret_cast<const float4*>(s + (size_t)(z + 1) * e.elems);
+        const float4 v2 = *reinterpret_cast<const float4*>(s + (size_t)(z + 2) * e.elems);
+        const float4 v3 = *reinterpret_cast<const float4*>(s + (size_t)(z + 3) * e.elems);
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+        acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+        acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+        acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+    }
+    for (; z < e.splits; ++z) {
         const float4 v = *reinterpret_cast<const float4*>(s + (size_t)z * e.elems);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }

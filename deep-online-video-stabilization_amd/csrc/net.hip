@@ -783,7 +783,8 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
 // train_bundle_nobm.py:155-160).  The plan must have been created with keep_activations = 1.
 // =========================================================================================================
 struct TrainLayout {
-    size_t bn_scale, bn_shift, bn_mean, bn_invstd, GA, GB, T1, T2, T3, fcg0, fcg1, partial, coef, wt, argmax, splitk, slabs, total;
+    size_t bn_scale, bn_shift, bn_mean, bn_invstd, GA, GB, T1, T2, T3, fcg0, fcg1, partial, fcpart, coef, wt, argmax, splitk, slabs, total;
+    size_t fcpart_floats;
     size_t splitk_bytes, slab_floats;
 };
 
@@ -811,6 +812,8 @@ static TrainLayout train_layout(const Net* net) {
         red = std::max(red, col_reduce_workspace_floats((long)u.out.N * u.out.H * u.out.W, u.depth));
     red = std::max(red, col_reduce_workspace_floats((long)net->t_c1.N * net->t_c1.H * net->t_c1.W, 64));
     L.partial = take(red);
+    L.fcpart_floats = (size_t)64 * net->N * 2048;            // fc_bwd_x partials: (Nout/32 <= 64 splits) x N x K
+    L.fcpart = take(L.fcpart_floats);
     L.coef = take(3 * std::max<size_t>(net->max_c, 2048));
     L.wt = take((size_t)net->packs.prefix[net->packs.n]);
     L.argmax = take((net->t_pool.size + 3) / 4);              // one byte per pooled element
@@ -968,7 +971,7 @@ static int run_backward_stage(const Net* net, const float* params, const float* 
             const float* yk = (k < 3) ? ws + net->t_fc[k].off : nullptr;            // output of layer k (ReLU mask), k < 3
             float* dx = fg[k & 1];
             rc = launch_fc_bwd(ws + fin[k]->off, params + net->fc_w[k], yk, dy, N, net->fc_dims[k], net->fc_dims[k + 1], k < 3,
-                               grads + net->fc_w[k], grads + net->fc_b[k], dx, st);
+                               grads + net->fc_w[k], grads + net->fc_b[k], dx, ws + L.fcpart, L.fcpart_floats, st);
             if (rc) return rc;
             dy = dx;
         }

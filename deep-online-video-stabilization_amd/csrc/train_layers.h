@@ -21,7 +21,7 @@ int launch_max_pool_argmax(const float* x, float* y, unsigned char* argmax, int 
                            int stride, int pt, int pl, hipStream_t st);
 int launch_gap_bwd(const float* dg, int N, int HW, int C, float* da, hipStream_t st);
 int launch_fc_bwd(const float* x, const float* w, const float* y, const float* dy, int M, int K, int Nout, int relu,
-                  float* dW, float* db, float* dx, hipStream_t st);
+                  float* dW, float* db, float* dx, float* scratch, size_t scratch_floats, hipStream_t st);
 int launch_weight_decay(const float* params, float* grads, const long* seg_off, const long* seg_len, const float* seg_coef,
                         int nseg, float gscale, float* loss_out, float* partial, hipStream_t st);
 int launch_adam(float* w, const float* g, const float* g2, float* m, float* v, long n, float lr_t, float b1, float b2,

@@ -7,7 +7,10 @@
 #include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------------
-// Column reductions over an [M][C] tensor, two stages (deterministic order):
+// Column reductions over an [M][C] tensor, two stages (deterministic order).  (Measured and dropped: ONE launch per reduction
+// with a last-block-done ticket doing the finalize -- with agent-scope release/acquire fences each reduction took 22 us
+// instead of 6 + 6, 512 blocks each paying a buffer_wbl2; in the fence-free sc1 store/load form the serial tail of the
+// last block still cost more than the second launch: 22.9 ms vs 21.9 ms per step.)
 //   MODE 0: (sum x, sum x^2)                           BN batch statistics
 //   MODE 1: (sum dz, sum dz*xhat), dz = g*(a>0)        BN+ReLU backward;  a = x*scale+shift, xhat = (x-mean)*invstd
 //   MODE 2: (sum g, -)                                 bias gradient
@@ -267,43 +270,42 @@ __global__ __launch_bounds__(256) void fc_bwd_w_kernel(const float* __restrict__
     if (k == 0) db[n] += bacc;
 }
 
-// dx[m][k] = sum_n dyr[m][n] W[n][k].  Block = 64 k-columns x 16 waves; wave w takes n = w, w+16, ... and the 16 partial
-// sums meet in LDS in wave order: no atomics, reproducible.  M is processed 8 rows at a time.
-__global__ __launch_bounds__(1024) void fc_bwd_x_kernel(const float* __restrict__ w, const float* __restrict__ y,
-                                                        const float* __restrict__ dy, int M, int K, int Nout, int relu,
-                                                        float* __restrict__ dx) {
-    __shared__ float part[16][8][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + lane;
+// dx[m][k] = sum_n dyr[m][n] W[n][k]: the n range is split over blockIdx.y into partial sums part[split][m][k] (plain
+// stores), which fc_bwd_x_reduce_kernel adds in split order -- no atomics, reproducible.
+__global__ __launch_bounds__(256) void fc_bwd_x_kernel(const float* __restrict__ w, const float* __restrict__ y,
+                                                       const float* __restrict__ dy, int M, int K, int Nout, int relu,
+                                                       int n_per_block, float* __restrict__ part) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const int nb = blockIdx.y * n_per_block, ne = min(Nout, nb + n_per_block);
     for (int m0 = 0; m0 < M; m0 += 8) {
         float acc[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-        if (k < K) {
-            for (int n = wv; n < Nout; n += 16) {
-                const float wvv = w[(size_t)n * K + k];
+        for (int n = nb; n < ne; ++n) {
+            const float wv = w[(size_t)n * K + k];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int m = m0 + i;
-                    if (m < M) {
-                        float d = dy[(size_t)m * Nout + n];
-                        if (relu && !(y[(size_t)m * Nout + n] > 0.f)) d = 0.f;
-                        acc[i] += d * wvv;
-                    }
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + i;
+                if (m < M) {
+                    float d = dy[(size_t)m * Nout + n];
+                    if (relu && !(y[(size_t)m * Nout + n] > 0.f)) d = 0.f;
+                    acc[i] += d * wv;
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) part[wv][i][lane] = acc[i];
-        __syncthreads();
-        if (wv < 8 && m0 + wv < M && k < K) {                    // wave i finishes row m0 + i
-            float s = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) s += part[q][wv][lane];
-            dx[(size_t)(m0 + wv) * K + k] = s;
-        }
-        __syncthreads();
+        for (int i = 0; i < 8; ++i)
+            if (m0 + i < M) part[((size_t)blockIdx.y * M + m0 + i) * K + k] = acc[i];
     }
+}
+__global__ __launch_bounds__(256) void fc_bwd_x_reduce_kernel(const float* __restrict__ part, int splits, long MK,
+                                                              float* __restrict__ dx) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MK) return;
+    float s = part[i];
+    for (int z = 1; z < splits; ++z) s += part[(size_t)z * MK + i];
+    dx[i] = s;
 }
 
 // Weight decay: loss += coef_seg * 0.5 * sum w^2 (block partials, summed in a fixed order by weight_decay_finalize_kernel),
@@ -465,12 +467,17 @@ int launch_gap_bwd(const float* dg, int N, int HW, int C, float* da, hipStream_t
 }
 
 int launch_fc_bwd(const float* x, const float* w, const float* y, const float* dy, int M, int K, int Nout, int relu,
-                  float* dW, float* db, float* dx, hipStream_t st) {
+                  float* dW, float* db, float* dx, float* scratch, size_t scratch_floats, hipStream_t st) {
     fc_bwd_w_kernel<<<dim3(cdiv(K, 256), Nout), 256, 0, st>>>(x, y, dy, M, K, Nout, relu, dW, db);
     SN_LAUNCH_CHECK("fc_bwd_w_kernel");
     if (dx != nullptr) {
-        fc_bwd_x_kernel<<<cdiv(K, 64), 1024, 0, st>>>(w, y, dy, M, K, Nout, relu, dx);
+        const int npb = 32, splits = cdiv(Nout, npb);
+        SN_REQUIRE(scratch != nullptr && scratch_floats >= (size_t)splits * M * K, "fc_bwd: scratch of %zu floats needed",
+                   (size_t)splits * M * K);
+        fc_bwd_x_kernel<<<dim3(cdiv(K, 256), splits), 256, 0, st>>>(w, y, dy, M, K, Nout, relu, npb, scratch);
         SN_LAUNCH_CHECK("fc_bwd_x_kernel");
+        fc_bwd_x_reduce_kernel<<<cdiv((long)M * K, 256), 256, 0, st>>>(scratch, splits, (long)M * K, dx);
+        SN_LAUNCH_CHECK("fc_bwd_x_reduce_kernel");
     }
     return STABNET_OK;
 }

@@ -90,7 +90,8 @@ class Trainer:
         _lib.call("stabnet_net_bn_grad_range", self.plan.handle, ctypes.byref(lo), ctypes.byref(hi))
         self.bn_bucket = (lo.value, hi.value)
         assert sorted(self.buckets + [self.bn_bucket])[0][0] == 0 and sum(b - a for a, b in self.buckets + [self.bn_bucket]) == nt
-        self.comm_timing = None               # bench: list of (start, end) event pairs on the comm stream, one per bucket
+        self.comm_timing = None               # bench: list of (start, end, bytes) on the comm stream, one per bucket
+        self.compute_done = []                # bench: one event per step on the compute stream, just before the join
 
     # ------------------------------------------------------------------------------------------------------
     def _tower_fwd(self, k: int, x):
@@ -186,6 +187,10 @@ class Trainer:
             mesh[k] = losses4
             self._tower_bwd(k, d_theta, reduce_buckets=(k == 0))
         if self.world > 1:
+            if self.comm_timing is not None:          # bench: when did backward itself finish (vs the last bucket's end)?
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(self.device))
+                self.compute_done.append(ev)
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         # regu_loss is counted once per tower (train_bundle_nobm.py:142): gradient coefficient 2 * regu_mul * live
         # (times world: the summed gradient is divided by world in the Adam kernel, the regulariser is not a rank sum)

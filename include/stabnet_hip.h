@@ -158,6 +158,11 @@ int stabnet_prof_record(const void* prof, int idx, int* kind, float* ms, double*
 int stabnet_prof_record_shape(const void* prof, int idx, int* shape4);
 const char* stabnet_prof_kind_name(int kind);
 
+/* ---- measurement helpers (bench.py: empirical peaks of the box beside the vendor peaks; not on the path) ---- */
+int stabnet_probe_mfma_f32(float* out /* blocks*256 floats */, int blocks, int iters, void* stream);
+double stabnet_probe_mfma_f32_flops(int blocks, int iters);
+int stabnet_probe_hbm_copy(const float* src, float* dst, long n_floats, void* stream);
+
 /* ---- training: backward of the warp / sampler and the loss kernels ---------------------------------------
  * These replace what TF autodiff generates for `opt.minimize(total_loss)` (train_bundle_nobm.py:160) over the ops
  * above.  floor / casts / comparisons carry no gradient (corners, black_pix, z sign, warp_pts indices are constants). */

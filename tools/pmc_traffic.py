@@ -22,12 +22,16 @@ def agg(d, counter):
     return {k: (len(v), sum(v.values()) / len(v)) for k, v in per.items()}
 
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_sha16  # noqa: E402  (the stamp bench.py checks before it reports `traffic`)
+
 fetch, write = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE")
-out = {}
+out = {"__meta__": {"csrc_sha16": csrc_sha16(), "command": "bench.py --steps 20 --warmup 5 (720p, batch 1)",
+                    "correction": "FETCH_SIZE x2 (gfx950 counts 128-B reads at 64 B), WRITE_SIZE as is; both in KB"}}
 for k, (n, fkb) in sorted(fetch.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
     wkb = write.get(k, (0, 0.0))[1]
     out[k] = {"launches": n, "fetch_size_kb_raw": fkb, "write_size_kb": wkb,
               "hbm_bytes_per_launch_corrected": (2.0 * fkb + wkb) * 1024.0}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-for k, v in list(out.items())[:12]:
+for k, v in [kv for kv in out.items() if kv[0] != "__meta__"][:12]:
     print("%-70s n=%5d  %.1f MB/launch" % (k[:70], v["launches"], v["hbm_bytes_per_launch_corrected"] / 1e6))

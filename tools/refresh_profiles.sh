@@ -1,15 +1,27 @@
 #!/bin/bash
-# Regenerates the judged artefacts under profiles/ on the GPU box (run through gpurun from the repo root).
+# Regenerates the judged artefacts under profiles/ on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r02'
+# Everything lands in gpurun_out/refresh/ and, named per round, in gpurun_out/profiles_<round>/ ready to copy to profiles/.
 set -o pipefail
 R=$PWD
+ROUND=${1:-r02}
 export TMPDIR=/tmp
 O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
-python bench.py > $O/bench.json 2> $O/bench.err || exit 1
+P=$R/gpurun_out/profiles_$ROUND; rm -rf $P; mkdir -p $P
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_infer -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train-leg > $O/stats_infer.json 2> $O/stats_infer.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train -- python $R/bench.py --mode train --steps 10 --warmup 3 --no-roofline > $O/stats_train.json 2> $O/stats_train.err || exit 1
+# PMC first: bench.py reads the traffic file (stamped with the kernel-source hash) when it prints `roofline.traffic`
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train-leg --no-roofline > /dev/null 2> $O/pmc_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train-leg --no-roofline > /dev/null 2> $O/pmc_write.err || exit 1
 cd $R
-python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm_traffic.json
-find $O -name "*kernel_stats.csv" | head
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $P/${ROUND}_pmc_hbm_traffic_bench720p.json || exit 1
+mkdir -p profiles && cp $P/${ROUND}_pmc_hbm_traffic_bench720p.json profiles/     # (on the box: so that the next command sees it)
+python bench.py > $P/${ROUND}_bench_720p.json 2> $O/bench.err || exit 1
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_infer -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train-leg > $O/stats_infer.json 2> $O/stats_infer.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train -- python $R/bench.py --mode train --steps 10 --warmup 3 --no-roofline > $O/stats_train.json 2> $O/stats_train.err || exit 1
+cd $R
+cp $(find $O/stats_infer -name "*kernel_stats.csv" | head -1) $P/${ROUND}_rocprofv3_kernel_stats_bench720p.csv
+cp $(find $O/stats_train -name "*kernel_stats.csv" | head -1) $P/${ROUND}_rocprofv3_kernel_stats_train_b8.csv
+python bench.py --mode train --steps 20 --warmup 5 > $P/${ROUND}_bench_train_1gpu.json 2> $O/train.err || exit 1
+python tools/layer_table.py > $P/${ROUND}_layers_720p.txt 2> $O/layers.err || true
+ls -la $P
