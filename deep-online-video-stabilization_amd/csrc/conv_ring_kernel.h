@@ -32,6 +32,18 @@ typedef const __attribute__((address_space(1))) void* sn_gbl_ptr_t;
 
 __device__ __attribute__((aligned(16))) float g_conv_zero_page[8];      // zero-initialised device storage
 
+#ifndef RING_STAMP
+#define RING_STAMP 0           // probe-only (tools/ring_probe.hip): per-workgroup s_memtime stamps of the launch's phases
+#endif
+#if RING_STAMP
+__device__ unsigned long long g_ring_stamps[4096 * 8];
+#define SN_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_ring_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SN_STAMP_RT(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_ring_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SN_STAMP(i) do { } while (0)
+#define SN_STAMP_RT(i) do { } while (0)
+#endif
+
 template <int MODE /* 0: no padding, 1: zero padding, 2: row-run A operand on a zero-BORDERED image (ConvArgs::rowrun) */>
 __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     constexpr int BM = 64, BN = 64, BK = 32;
@@ -39,6 +51,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     __shared__ __attribute__((aligned(16))) float ring[3 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SN_STAMP(0); SN_STAMP_RT(4);
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.Cout + BN - 1) / BN;
     const int tiles_mn = tiles_m * tiles_n;
@@ -286,6 +299,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     if (remaining > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SN_BARRIER();
+    SN_STAMP(1);
     issue(2);
     SN_READ0(0, 0);
 
@@ -337,8 +351,13 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         if (tile_done) {
             if (more) SN_WAIT0();                          // the next tile's first fragments: landed before the epilogue code
             else SN_BARRIER();                             // (otherwise the barrier above already retired slot SLOT)
+            SN_STAMP(2);
             conv_epilogue<1, 1>(acc, p, c_m0 + wm * 32, c_n0 + wn * 32, lane, c_z,
                                 lds_base + (unsigned)(OFF + wave * SN_EPI_WAVE_BYTES));
+#if RING_STAMP
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SN_STAMP(3); SN_STAMP_RT(5);
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
             ct += t_stride;

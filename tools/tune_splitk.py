@@ -16,6 +16,8 @@ ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os
 ap.add_argument("--reps", type=int, default=16)
 ap.add_argument("--gap-us", type=float, default=2.6, help="average launch gap charged to every extra (reduce) launch")
 ap.add_argument("--skip-train", action="store_true")
+ap.add_argument("--infer-sizes", default="720x1280", help="comma list of HxW deploy workloads, e.g. 720x1280,1080x1920,288x512,256x256")
+ap.add_argument("--merge", action="store_true", help="keep the entries of the existing table for shapes not measured in this run")
 a = ap.parse_args()
 L = _lib.lib()
 CANDS = [1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20]
@@ -58,9 +60,12 @@ def set_table(table):
         L.stabnet_conv_tuning_table_set(M, N, K, kh, ring, s)
 
 
+INFER_HW = (720, 1280)
+
+
 def run_infer(table):
     set_table(table)
-    H, W = 720, 1280
+    H, W = INFER_HW
     cfg = Config(height=H, width=W)
     P = synthetic.make_params(cfg, 0, 0.2)
     clip = torch.from_numpy(synthetic.make_clip(H, W, 4, 1234)).cuda()
@@ -128,7 +133,17 @@ def tune(run, label):
     return best
 
 
-table = tune(run_infer, "deploy 720p batch 1")
+table = {}
+if a.merge and os.path.exists(a.out):
+    import re
+    for m in re.finditer(r"\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},", open(a.out).read()):
+        v = [int(x) for x in m.groups()]
+        if v[0] > 0:
+            table[tuple(v[:5])] = v[5]
+for hw in a.infer_sizes.split(","):
+    INFER_HW = tuple(int(v) for v in hw.split("x"))
+    for k, v in tune(run_infer, "deploy %dx%d batch 1" % (INFER_HW[1], INFER_HW[0])).items():
+        table[k] = v
 if not a.skip_train:
     t2 = tune(run_train, "train 8 x 288x512")
     for k, v in t2.items():
@@ -136,7 +151,8 @@ if not a.skip_train:
 L.stabnet_conv_tuning_table_set(-1, 0, 0, 0, 0, 0)
 with open(a.out, "w") as f:
     f.write("// Measured split-K choices {M, Cout, K, KH, ring, splitk}; GENERATED by tools/tune_splitk.py on MI355X -- do not edit.\n")
-    f.write("// Workloads: deploy 1280x720 batch 1, training 8 pairs at 288x512 (forward with BN prologue: ring 0; dgrad: ring 1).\n")
+    f.write("// Workloads: deploy batch 1 at 1280x720, 1920x1080, 512x288 and 256x256 (BASELINE configs[1], [4], the reference's native\n")
+    f.write("// size, configs[0]); training 8 pairs at 288x512 (forward with BN prologue: ring 0; dgrad: ring 1).\n")
     f.write("// Per shape: the smallest split within 1 % of the fastest measured one (kernel + reduce launch + launch gap, in-network).\n")
     f.write("static const TuneEntry g_tuning_builtin[] = {\n")
     for (M, N, K, kh, ring), s in sorted(table.items()):
