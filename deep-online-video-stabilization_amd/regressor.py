@@ -150,7 +150,7 @@ def get_resnet(x_tensor, reuse=None, is_training=False, x_batch_size=None, *, re
     `x_batch_size` are graph-construction arguments of TF with no counterpart here (the batch is the plan's N)."""
     theta = regressor.forward_train(x_tensor) if is_training else regressor(x_tensor)
     cfg = regressor.cfg
-    losses4 = empty((4,), theta)
+    losses4 = empty((4,), theta)                 # {id2_loss, black_pos, distortion, consistency}; d_theta not wanted (NULL)
     _lib.call("stabnet_mesh_losses", ptr(theta), 0, theta.shape[0], cfg.grid_h, cfg.grid_w, cfg.do_crop_rate, cfg.id_mul,
               0.0, 0.0, 0.0, 0.0, 0.0, ptr(losses4), 0, stream_ptr(theta.device), device=theta.device)
     id2 = losses4[0]

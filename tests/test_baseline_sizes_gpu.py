@@ -69,45 +69,68 @@ def test_deploy_step_720p_matches_oracle(cuda):
 
 
 def test_config1_clip_256_stream_vs_golden(cuda):
-    """configs[0]: the 64-frame 256x256 clip through StabNetStream (graph replay on), against the oracle trajectory
-    committed by oracle/make_golden_clip.py.  Two layers of checking per frame:
-      (1) free-running: theta / strided map + pixel samples / sums of the fed-back loop stay within the stated tolerance
-          of the oracle's over all 63 steps (the recurrence does not amplify the float32 summation-order differences);
-      (2) teacher-forced: with the golden theta of that frame, the GPU warp reproduces the golden CRC32 of x_map, y_map,
-          black and out -- the per-frame checksums of SURVEY 8d Config 1, bit for bit."""
+    """configs[0]: the 64-frame 256x256 clip through StabNetStream, against the oracle's restatement of the deploy loop
+    (whose trajectory is committed by oracle/make_golden_clip.py).  Three layers of checking:
+      (1) per frame, from the ORACLE's ring state (teacher-forced recurrence: the GPU ring is loaded with the oracle's 32
+          frames + 32 masks before every step): theta <= 2e-5, maps <= 1e-4, black flips only where the map is within the
+          tolerance of +-1, warped pixels within the Lipschitz bound, and the push lands in the right slot -- the
+          single-frame bars, on 63 realistic recurrent states (masks, blacked borders, fed-back frames);
+      (2) with the golden theta of that frame, the GPU warp reproduces the golden CRC32 of x_map, y_map, black and out --
+          the per-frame checksums of SURVEY 8d Config 1, bit for bit;
+      (3) free-running (graph replay on): the first frames agree to float32 rounding; afterwards the loop's discontinuities
+          (binary black mask, clipped-corner sampler) turn a 1e-7 difference into a flipped pixel sooner or later (frame 10
+          here), from where two float32 implementations follow nearby but different trajectories (measured: theta within
+          1.2e-3 over the clip).  Any pair of float32 implementations shows this, so the free-running bar is 'stays close',
+          not a rounding-level one."""
     from stabnet_amd import synthetic, warp
     from stabnet_amd.config import Config
     from stabnet_amd.deploy import StabNetStream
     g = np.load(GOLDEN)
     H, W, Tn, clip_seed, weight_seed, stride = (int(v) for v in g["meta"])
-    cfg = Config(height=H, width=W)
+    cfg, ocfg = Config(height=H, width=W), O.Config(height=H, width=W)
     P = synthetic.make_params(cfg, seed=weight_seed, theta_scale=float(g["theta_scale"]))
     clip = synthetic.make_clip(H, W, Tn, seed=clip_seed, margin=64)
     dclip = torch.from_numpy(clip).to(cuda)
-    s = StabNetStream(P, H, W, cfg, streams=1, device=cuda, use_graph=True)
-    s.start(dclip[0:1])
-    sl = (slice(0, H, stride), slice(0, W, stride))
-    worst = {"theta": 0.0, "map": 0.0, "out": 0.0}
+    forced = StabNetStream(P, H, W, cfg, streams=1, device=cuda)
+    free = StabNetStream(P, H, W, cfg, streams=1, device=cuda, use_graph=True)
+    forced.start(dclip[0:1]); free.start(dclip[0:1])
+    ring = O.DeployRing(clip[0], ocfg)
+    depth = forced.depth
+    free_err = []
     for t in range(1, Tn):
-        r = s.step(dclip[t:t + 1])
-        th = r["theta"].cpu().numpy()[0]
-        xm, ym = r["x_map"].cpu().numpy()[0, :, :, 0], r["y_map"].cpu().numpy()[0, :, :, 0]
-        out, bl = r["output"].cpu().numpy()[0, :, :, 0], r["black_pix"].cpu().numpy()[0]
-        worst["theta"] = max(worst["theta"], float(np.abs(th - g["theta"][t - 1]).max()))
-        worst["map"] = max(worst["map"], float(np.abs(xm[sl] - g["x_map_s"][t - 1]).max()),
-                           float(np.abs(ym[sl] - g["y_map_s"][t - 1]).max()))
-        worst["out"] = max(worst["out"], float(np.abs(out[sl] - g["out_s"][t - 1]).max()))
-        assert abs(float(bl.sum()) - g["sums"][t - 1, 2]) <= 64, t               # black pixels: edge flips only
-        assert abs(float(xm.sum(dtype=np.float64)) - g["sums"][t - 1, 0]) <= 1e-4 * H * W, t
+        # (1) load the oracle's history: lag i lives in slot (head - i) mod depth
+        head = forced.head
+        fr = np.stack([ring.frames[-i][0, :, :, 0] for i in range(1, depth + 1)])
+        mk = np.stack([ring.masks[-i][0, :, :, 0] for i in range(1, depth + 1)])
+        slots = [(head - i) % depth for i in range(1, depth + 1)]
+        forced.frames_ring[0, slots] = torch.from_numpy(fr).to(cuda)
+        forced.masks_ring[0, slots] = torch.from_numpy(mk).to(cuda)
+        got = forced.step(dclip[t:t + 1])
+        ref, frame = O.deploy_step(ring, clip[t], P, ocfg)
+        # the oracle re-run here and the committed trajectory (made on another host: other BLAS blocking / thread count) are two
+        # float32 implementations in the sense of (3) as well: identical at first, nearby later (measured 3.6e-5 at frame 49)
+        assert np.abs(ref["theta"][0] - g["theta"][t - 1]).max() < (1e-6 if t <= 5 else 1e-2), t
+        th = got["theta"].cpu().numpy()
+        assert np.abs(th - ref["theta"]).max() <= 2e-5, (t, float(np.abs(th - ref["theta"]).max()))
+        xm, ym = got["x_map"].cpu().numpy(), got["y_map"].cpu().numpy()
+        assert np.abs(xm - ref["x_map"]).max() < 1e-4 and np.abs(ym - ref["y_map"]).max() < 1e-4, t
+        flips = got["black_pix"].cpu().numpy() != ref["black_pix"]
+        edge = (np.abs(np.abs(ref["x_map"][..., 0]) - 1) < 1e-4) | (np.abs(np.abs(ref["y_map"][..., 0]) - 1) < 1e-4)
+        assert not (flips & ~edge).any(), t
+        _lipschitz_pixel_check(clip[t], got["output"].cpu().numpy(), ref, xm, ym, H, W)
+        assert torch.equal(forced.frames_ring[0, head], forced.frame_fb[0]) and forced.head == (head + 1) % depth
         # (2) teacher-forced checksums
         r2 = warp.warp_from_theta(dclip[t].reshape(1, H, W, 1), torch.from_numpy(g["theta"][t - 1:t]).to(cuda), cfg)
         crc = [zlib.crc32(np.ascontiguousarray(r2[k].cpu().numpy(), np.float32).tobytes())
                for k in ("x_map", "y_map", "black_pix", "output")]
         assert crc == [int(c) for c in g["crc"][t - 1]], (t, crc)
-    # tolerances: theta 5e-5 (63 recurrent steps; single-frame bar is 2e-5), maps 3e-4 normalised (0.04 px), samples 2e-2
-    # of the [-0.5, 0.5] range at the strided positions (Lipschitz in the map error)
-    assert worst["theta"] <= 5e-5 and worst["map"] <= 3e-4 and worst["out"] <= 2e-2, worst
-    assert s._graph is not None
+        # (3) free-running
+        rf = free.step(dclip[t:t + 1])
+        free_err.append(float(np.abs(rf["theta"].cpu().numpy()[0] - g["theta"][t - 1]).max()))
+        assert torch.isfinite(rf["output"]).all()
+    print("config-1 clip, free-running theta deviation per frame:", " ".join("%.0e" % e for e in free_err))
+    assert max(free_err[:5]) <= 2e-5 and max(free_err) <= 1e-2, free_err
+    assert free._graph is not None
 
 
 def _train_setup(N, H, W):

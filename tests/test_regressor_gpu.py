@@ -125,3 +125,51 @@ def test_wrong_pointer_is_an_error_not_a_fault(cuda):
     with pytest.raises(_lib.StabnetError, match="device"):
         _lib.call("stabnet_backbone_fwd_infer", reg.plan.handle, host_params.data_ptr(), reg.fold.data_ptr(), xt.data_ptr(),
                   theta.data_ptr(), reg.workspace.data_ptr(), reg.workspace.numel(), torch.cuda.current_stream().cuda_stream, 0)
+
+
+def test_get_resnet_training_and_inference_branches(cuda):
+    """get_resnet(x, reuse, is_training, n) (s_net_bundle_nobm.py:250-264): is_training=True is the batch-statistics branch of
+    :301 (and updates the moving averages, slim UPDATE_OPS), False the moving-average branch of :302; both return
+    (theta, id2_loss, id2_loss) with id2_loss = mean|theta| * id_mul (:263-264)."""
+    from stabnet_amd.regressor import Regressor, get_resnet
+    N, H, W = 2, 64, 96
+    cfg, ocfg, P, x = _setup(N, H, W)
+    xt = torch.from_numpy(x).to(cuda)
+    reg = Regressor(P, N, H, W, cfg)
+    th_i, id_i, id2_i = get_resnet(xt, None, False, N, regressor=reg)
+    ref_i, _, rid_i = O.get_resnet(x, P, ocfg, training=False)
+    assert np.abs(th_i.cpu().numpy() - ref_i).max() <= 2e-5
+    assert float(id2_i) == pytest.approx(float(rid_i), rel=1e-4) and float(id_i) == float(id2_i)
+    mov0 = reg.params[reg.plan.n_trainable:].clone()
+    stats = {}
+    th_t, _, id2_t = get_resnet(xt, None, True, N, regressor=reg)
+    ref_t, _, rid_t = O.get_resnet(x, P, ocfg, training=True, stats_out=stats)
+    assert np.abs(th_t.cpu().numpy() - ref_t).max() <= 5e-5
+    assert float(id2_t) == pytest.approx(float(rid_t), rel=1e-3)
+    assert np.abs(ref_t - ref_i).max() > 1e-3                       # the two branches do differ on this input
+    # the moving averages moved towards the batch statistics with decay 0.997
+    q = reg.plan.unpack(reg.params.cpu().numpy())
+    name = "resnet_v2_50/block2/unit_1/bottleneck_v2/conv1/BatchNorm"
+    want = P[name + "/moving_variance"] - (P[name + "/moving_variance"] - stats[name][1]) * (1 - cfg.bn_decay)
+    assert np.abs(q[name + "/moving_variance"] - want).max() < 1e-5
+    assert not torch.equal(mov0, reg.params[reg.plan.n_trainable:])
+
+
+def test_mirror_repacking_kernels(cuda):
+    """x_tensor[..., 12:13] and img = [x_map, y_map] are library kernels (no torch arithmetic on the path)."""
+    from stabnet_amd import warp
+    from stabnet_amd.config import Config
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 9, 11, 13, generator=g).to(cuda)
+    for c in (0, 12):
+        assert torch.equal(warp.slice_channel(x, c), x[..., c:c + 1])
+    cfg = Config(height=32, width=64)
+    theta = (torch.randn(2, 50, generator=g) * 0.05).to(cuda)
+    U = torch.rand(2, 32, 64, 1, generator=g).to(cuda)
+    pts1, pts2, Hs = warp.get_4_pts(theta, 2, cfg, with_Hs=True)
+    out, black, img, Hs2 = warp.transformer(U, pts2, cfg=cfg, return_Hs=True)
+    r = warp.warp_from_theta(U, theta, cfg)
+    assert torch.equal(img[..., 0], r["x_map"][..., 0]) and torch.equal(img[..., 1], r["y_map"][..., 0]) and torch.equal(out, r["output"])
+    ocfg = O.Config(height=32, width=64)
+    p1, p2 = O.get_4_pts(theta.cpu().numpy(), ocfg)
+    assert np.array_equal(pts1.cpu().numpy(), p1) and np.array_equal(pts2.cpu().numpy(), p2)
