@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--train-steps", type=int, default=10, help="steps of the extra train leg of the default run")
     ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the frame eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the SECONDARY bf16-operand line (never the headline)")
     return ap.parse_args()
 
 
@@ -367,6 +368,34 @@ def main():
                              "traffic": pmc_traffic("warp_sample_kernel<4, 1>", (H, W, S, args.refine) == (720, 1280, 1, 1))[0]}
         roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], (H, W, S, args.refine) == (720, 1280, 1, 1))
 
+    bf16 = None
+    if rank == 0 and not args.no_bf16_leg:
+        # SECONDARY, labelled: the same frames with the conv operands rounded to bf16 at fragment-read time (fp32 tensors,
+        # fp32 accumulate).  Reported beside the fp32 headline with the deviation it costs; `value` stays the fp32 figure.
+        th32 = stream.theta.clone()
+        s16 = StabNetStream(P, H, W, cfg, streams=S, device=dev, refine=args.refine, use_graph=not args.no_graph,
+                            bf16_operands=True)
+        s16.start(frames[0])
+        s16.frames_ring.copy_(stream.frames_ring); s16.masks_ring.copy_(stream.masks_ring); s16.head_dev.copy_(stream.head_dev)
+        tt = t
+        for _ in range(max(3, args.warmup // 2)):
+            s16.step(frames[tt % args.clip_frames]); tt += 1
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            s16.step(frames[tt % args.clip_frames]); tt += 1
+        torch.cuda.synchronize()
+        el16 = time.perf_counter() - t2
+        # deviation on ONE frame from identical ring state
+        s16.frames_ring.copy_(stream.frames_ring); s16.masks_ring.copy_(stream.masks_ring); s16.head_dev.copy_(stream.head_dev)
+        a = stream.step(frames[t % args.clip_frames])["theta"].clone()
+        stream.frames_ring.copy_(s16.frames_ring); stream.masks_ring.copy_(s16.masks_ring); stream.head_dev.copy_(s16.head_dev)
+        b = s16.step(frames[t % args.clip_frames])["theta"].clone()
+        bf16 = {"label": "SECONDARY: bf16 conv operands (rounded at fragment-read time), fp32 tensors + fp32 accumulate; "
+                         "not the reference's precision, never the headline",
+                "value": args.steps * S / el16, "unit": "frames/s", "ms_per_step": 1e3 * el16 / args.steps,
+                "theta_max_abs_dev_vs_fp32": float((a - b).abs().max().item()), "theta_scale": float(a.abs().max().item())}
+        del s16, th32
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(P, clip, H, W, args.cpu_baseline_seconds)
@@ -416,6 +445,8 @@ def main():
                 line["roofline_warp"]["frac_of_empirical_peak"] = roof_warp["achieved"] / peaks["hbm_copy_gbps"]
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        if bf16 is not None:
+            line["secondary_bf16_operands"] = bf16
         if train is not None:
             line["train"] = train          # BASELINE configs[2]/[3] measured in the same run (second metric)
         print(json.dumps(line))

@@ -139,7 +139,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvA
 // MODE 0: no padding and no dilation (1x1 convs, any stride): every tap of every row < M is in frame -> no masks.
 // MODE 1: zero padding: a per-row bit mask (one bit per filter tap, built once) says which taps are in frame.
 // MODE 2: dilated input (dgrad of a strided conv): validity and address are recomputed per tap (slow path).
-template <int BM, int BN, int BK, int WM, int WN, int MODE, int NBUF = 2>
+template <int BM, int BN, int BK, int WM, int WN, int MODE, int NBUF = 2, int BF16 = 0>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
     constexpr int PITCH = BK + 4;
     constexpr int WAVES_N = BN / WN;
@@ -323,6 +323,34 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
         if (ks + 1 < ks_end) load_tiles();                // global loads in flight under the MFMAs
         const float* Ab = smem + buf * STAGE + (wm * WM) * PITCH + frag_off;
         const float* Bb = smem + buf * STAGE + (BM + wn * WN) * PITCH + frag_off;
+        if constexpr (BF16) {
+            // bf16-operand mode (ConvArgs::bf16_operands): two 8-deep fragment pairs -> one v_mfma_f32_32x32x16_bf16
+            typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+            typedef float fl4 __attribute__((ext_vector_type(4)));
+            static_assert(BK % 16 == 0 || !BF16, "bf16 operands need BK % 16 == 0");
+#pragma unroll
+            for (int kp = 0; kp < BK / 16; ++kp) {
+                fl4 al[TM], ah[TM], bl[TN], bh[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    al[i] = *reinterpret_cast<const fl4*>(Ab + i * 32 * PITCH + (2 * kp) * 8);
+                    ah[i] = *reinterpret_cast<const fl4*>(Ab + i * 32 * PITCH + (2 * kp + 1) * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bl[j] = *reinterpret_cast<const fl4*>(Bb + j * 32 * PITCH + (2 * kp) * 8);
+                    bh[j] = *reinterpret_cast<const fl4*>(Bb + j * 32 * PITCH + (2 * kp + 1) * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_shufflevector(__builtin_convertvector(al[i], bf4), __builtin_convertvector(ah[i], bf4), 0, 1, 2, 3, 4, 5, 6, 7),
+                            __builtin_shufflevector(__builtin_convertvector(bl[j], bf4), __builtin_convertvector(bh[j], bf4), 0, 1, 2, 3, 4, 5, 6, 7),
+                            acc[i][j], 0, 0, 0);
+            }
+        } else {
         // fragment reads run one kk ahead of the MFMAs that consume them (LDS latency hidden under the matrix work)
         float4 af[2][TM], bf[2][TN];
 #pragma unroll
@@ -355,6 +383,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
         for (int kk = 0; kk < BK / 8; ++kk) {
             if (kk + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+        }
         }
         if (NBUF == 1) __syncthreads();                   // single LDS stage: everyone is done reading it
         if (ks + 1 < ks_end) store_tiles(NBUF == 2 ? (buf ^ 1) : 0);

@@ -44,7 +44,11 @@ __device__ unsigned long long g_ring_stamps[4096 * 8];
 #define SN_STAMP_RT(i) do { } while (0)
 #endif
 
-template <int MODE /* 0: no padding, 1: zero padding, 2: row-run A operand on a zero-BORDERED image (ConvArgs::rowrun) */>
+typedef __bf16 sn_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 sn_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int MODE /* 0: no padding, 1: zero padding, 2: row-run A operand on a zero-BORDERED image (ConvArgs::rowrun) */,
+          int BF16 = 0 /* 1: fragments rounded to bf16 at read time, v_mfma_f32_32x32x16_bf16 (ConvArgs::bf16_operands) */>
 __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     constexpr int BM = 64, BN = 64, BK = 32;
     constexpr int STAGE = (BM + BN) * BK;                  // floats
@@ -308,6 +312,42 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         constexpr int SLOT = decltype(slot_c)::value;
         constexpr int OFF = SLOT * STAGE * 4;
         constexpr int OFF_NEXT = ((SLOT + 1) % 3) * STAGE * 4;
+        bool tile_done, more;
+        if constexpr (BF16) {
+            // bf16-operand mode: the four 8-deep fragment pairs of the stage feed TWO v_mfma_f32_32x32x16_bf16.  A lane half
+            // holds k = {4h..4h+3} of fragment kk and of fragment kk+1: a permutation of the 16 k of the instruction that is
+            // the same for A and B, so the product sum is the same set of terms.  The matrix pipe is no longer the limit
+            // here (64 instead of 1024 cycles per stage): the LDS-DMA stream is.
+            SN_WAIT0();
+            const sn_bf16x4 al = __builtin_convertvector(a0, sn_bf16x4), bl = __builtin_convertvector(b0, sn_bf16x4);
+            SN_READ1(1, OFF);
+            SN_WAIT1();
+            const sn_bf16x4 ah = __builtin_convertvector(a1, sn_bf16x4), bh = __builtin_convertvector(b1, sn_bf16x4);
+            SN_READ0(2, OFF);
+            SN_READ1(3, OFF);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(al, ah, 0, 1, 2, 3, 4, 5, 6, 7),
+                                                                __builtin_shufflevector(bl, bh, 0, 1, 2, 3, 4, 5, 6, 7), acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            SN_WAIT0();
+            SN_WAIT1();                                        // every fragment of this stage is in registers
+            const sn_bf16x4 cl = __builtin_convertvector(a0, sn_bf16x4), dl = __builtin_convertvector(b0, sn_bf16x4);
+            const sn_bf16x4 ch = __builtin_convertvector(a1, sn_bf16x4), dh = __builtin_convertvector(b1, sn_bf16x4);
+            __builtin_amdgcn_sched_barrier(0);
+            --remaining;
+            tile_done = (--c_left == 0);
+            more = remaining > 0;
+            const bool feed = more && !tile_done;
+            if (more) {
+                if (remaining > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SN_BARRIER();
+                SN_READ0(0, OFF_NEXT);
+            }
+            if (feed) { issue_part(SLOT, 0); issue_part(SLOT, 1); issue_part(SLOT, 2); issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0); }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(cl, ch, 0, 1, 2, 3, 4, 5, 6, 7),
+                                                                __builtin_shufflevector(dl, dh, 0, 1, 2, 3, 4, 5, 6, 7), acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
         SN_WAIT0();
         SN_MFMA1(a0, b0, x);
         SN_READ1(1, OFF);
@@ -329,8 +369,9 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         SN_WAIT1();                                        // every fragment of this stage is in registers
         SN_MFMA1(a1, b1, x);
         --remaining;
-        const bool tile_done = (--c_left == 0);
-        const bool more = remaining > 0, feed = more && !tile_done;
+        tile_done = (--c_left == 0);
+        more = remaining > 0;
+        const bool feed = more && !tile_done;
         if (more) {
             // stage k+1 has landed for THIS wave when at most stage k+2's 4 DMAs are outstanding.  (Epilogue stores of
             // an earlier tile may be in flight too: the counter retires in order, so the wait is then stricter, never weaker.)
@@ -348,6 +389,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
         if (feed) { issue_part(SLOT, 2); __builtin_amdgcn_sched_barrier(0); }
         SN_MFMA1(a1, b1, w);
         if (feed) { issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0); }
+        }
         if (tile_done) {
             if (more) SN_WAIT0();                          // the next tile's first fragments: landed before the epilogue code
             else SN_BARRIER();                             // (otherwise the barrier above already retired slot SLOT)

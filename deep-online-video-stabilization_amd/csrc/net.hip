@@ -99,6 +99,7 @@ struct BnInfo { long chan_off; int C; long tensor_off; long M; int H, W; };
 struct Net {
     int N, H, W, in_ch, in_ch_pad, n_theta, keep_all;
     int stem_rowrun = 0, in_ch_act = 0;            // inference plans read the 13-channel stack directly (ring kernel MODE 2)
+    int bf16_operands = 0;                        // secondary fast mode of the inference forward (stabnet_net_set_bf16_operands)
     size_t stem_w_floats = 0;
     struct MergeInfo { long off; int depth, dbn; long b_sc, bn1; };
     std::vector<MergeInfo> merges;                // merged shortcut|conv1 launches of the inference plan
@@ -470,6 +471,7 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
                     a.relu_out = 0;
                 }
                 a.partial = splitk;
+                a.bf16_operands = net->bf16_operands;
                 rc = conv_launch(a, st, prof);
                 break;
             }
@@ -592,6 +594,17 @@ int stabnet_net_create(void** out, int N, int H, int W, int in_ch, int n_theta, 
 }
 
 void stabnet_net_destroy(void* net) { delete static_cast<Net*>(net); }
+
+/* SECONDARY fast mode of the inference forward, off by default: the conv operands are rounded to
+ * bf16 when the fragments are read (fp32 tensors in memory, fp32 accumulate, v_mfma_f32_32x32x16_bf16).  The reference is
+ * fp32 end to end, so this mode has its own, looser parity bar (tests/test_bf16_mode_gpu.py) and is never the headline. */
+int stabnet_net_set_bf16_operands(void* netp, int on) {
+    Net* net = static_cast<Net*>(netp);
+    SN_REQUIRE(net != nullptr, "set_bf16_operands: null net");
+    SN_REQUIRE(!net->keep_all || !on, "set_bf16_operands: inference plans only (training stays fp32)");
+    net->bf16_operands = on ? 1 : 0;
+    return STABNET_OK;
+}
 
 int stabnet_net_num_params(const void* net) { return net ? (int)static_cast<const Net*>(net)->params.size() : -1; }
 

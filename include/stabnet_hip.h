@@ -99,6 +99,9 @@ int stabnet_conv2d_fwd_ex(const float* x, const float* w_ohwi, const float* bias
  * (conv: un-padded Cin). */
 int stabnet_net_create(void** net, int N, int H, int W, int in_ch, int n_theta, int keep_activations);
 void stabnet_net_destroy(void* net);
+/* SECONDARY fast mode of the inference forward (off by default, never the headline): conv operands
+ * rounded to bf16 at fragment-read time (fp32 tensors in memory, fp32 accumulate).  Own, looser parity bar. */
+int stabnet_net_set_bf16_operands(void* net, int on);
 int stabnet_net_num_params(const void* net);
 int stabnet_net_param_info(const void* net, int idx, char* name, int name_cap, long* offset, int* kind, int* dims4,
                            int* aux);
