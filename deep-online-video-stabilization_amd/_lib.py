@@ -11,7 +11,8 @@ import re
 import torch  # noqa: F401  (plumbing: device memory, streams)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstabnet_hip.so")
+# STABNET_LIB: debug switch for A/B runs against another build of the library (symbols it lacks are skipped)
+LIB_PATH = os.environ.get("STABNET_LIB") or os.path.join(_HERE, "libstabnet_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "stabnet_hip.h")
 
 _lib = None
@@ -58,6 +59,8 @@ def lib():
                 "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
         L = ctypes.CDLL(LIB_PATH)
         for name, restype, argtypes in declared_symbols():
+            if os.environ.get("STABNET_LIB") and not hasattr(L, name):
+                continue
             fn = getattr(L, name)          # AttributeError if the header and the library disagree
             fn.restype = restype
             fn.argtypes = argtypes

@@ -33,16 +33,17 @@ struct ConvArgs {
                              //    real (unpadded) pixel stride; no prologue.
     int in_scale_expected;   // plan-time hint: 1 if the launch will carry an input BN prologue (in_scale is bound later)
     int xcd_swizzle;         // 1: remap workgroup ids so each XCD (own 4 MiB L2) works on a contiguous run of M tiles
-    int bf16_operands;       // 1: SECONDARY fast mode: A and B fragments are rounded to bf16 when they are read
-                             //    from LDS and multiplied by v_mfma_f32_32x32x16_bf16 (fp32 accumulate; tensors stay fp32 in memory).
-                             //    Never the default: the reference is fp32 end to end.
 };
 
 // Chooses tile shape / split-K and returns the workspace bytes the launch needs (0 if none).
 size_t conv_plan(ConvArgs& a);
 // Enqueues the convolution (and the split-K reduction when a.splitk > 1).
 struct Prof;
-int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof = nullptr);
+// bf16_operands = 1: SECONDARY fast mode: A and B fragments are rounded to bf16 when they are read from
+// LDS and multiplied by v_mfma_f32_32x32x16_bf16 (fp32 accumulate; tensors stay fp32 in memory).  Never the default: the
+// reference is fp32 end to end.  (A launch argument, not a ConvArgs field: the fp32 kernels' argument block -- and with it their
+// register allocation -- stays exactly what it was; an extra field cost the fp32 path 1 %.)
+int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof = nullptr, int bf16_operands = 0);
 
 // Exact unsigned division by an invariant divisor d >= 1 for numerators n < 2^31 (Granlund-Montgomery round-up form):
 //   l = ceil(log2 d), mul = floor(2^32 (2^l - d) / d) + 1, n / d = (mulhi(mul, n) + n) >> l.

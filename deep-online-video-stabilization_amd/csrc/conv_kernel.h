@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
         const float* Ab = smem + buf * STAGE + (wm * WM) * PITCH + frag_off;
         const float* Bb = smem + buf * STAGE + (BM + wn * WN) * PITCH + frag_off;
         if constexpr (BF16) {
-            // bf16-operand mode (ConvArgs::bf16_operands): two 8-deep fragment pairs -> one v_mfma_f32_32x32x16_bf16
+            // bf16-operand mode (conv_launch's bf16_operands): two 8-deep fragment pairs -> one v_mfma_f32_32x32x16_bf16
             typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
             typedef float fl4 __attribute__((ext_vector_type(4)));
             static_assert(BK % 16 == 0 || !BF16, "bf16 operands need BK % 16 == 0");

@@ -48,7 +48,7 @@ typedef __bf16 sn_bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 sn_bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int MODE /* 0: no padding, 1: zero padding, 2: row-run A operand on a zero-BORDERED image (ConvArgs::rowrun) */,
-          int BF16 = 0 /* 1: fragments rounded to bf16 at read time, v_mfma_f32_32x32x16_bf16 (ConvArgs::bf16_operands) */>
+          int BF16 = 0 /* 1: fragments rounded to bf16 at read time, v_mfma_f32_32x32x16_bf16 (conv_launch's bf16_operands) */>
 __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     constexpr int BM = 64, BN = 64, BK = 32;
     constexpr int STAGE = (BM + BN) * BK;                  // floats

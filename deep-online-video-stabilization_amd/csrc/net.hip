@@ -471,8 +471,7 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
                     a.relu_out = 0;
                 }
                 a.partial = splitk;
-                a.bf16_operands = net->bf16_operands;
-                rc = conv_launch(a, st, prof);
+                rc = conv_launch(a, st, prof, net->bf16_operands);
                 break;
             }
             case S_POOL:
@@ -571,15 +570,19 @@ const char* stabnet_prof_kind_name(int kind) {
         case PK_KERNEL_WGRAD: return "conv_wgrad_f32_kernel";
         default: break;
     }
-    if (kind == PK_KERNEL_CONV_RING) return "conv_ring_f32_kernel<0>";
-    if (kind == PK_KERNEL_CONV_RING + 1) return "conv_ring_f32_kernel<1>";
-    if (kind == PK_KERNEL_CONV_RING + 2) return "conv_ring_f32_kernel<2>";
+    // names as rocprofv3 prints the template instantiation <MODE, BF16>
+    if (kind == PK_KERNEL_CONV_RING) return "conv_ring_f32_kernel<0, 0>";
+    if (kind == PK_KERNEL_CONV_RING + 1) return "conv_ring_f32_kernel<1, 0>";
+    if (kind == PK_KERNEL_CONV_RING + 2) return "conv_ring_f32_kernel<2, 0>";
+    if (kind == PK_KERNEL_CONV_RING + 3) return "conv_ring_f32_kernel<0, 1>";
+    if (kind == PK_KERNEL_CONV_RING + 4) return "conv_ring_f32_kernel<1, 1>";
+    if (kind == PK_KERNEL_CONV_RING + 5) return "conv_ring_f32_kernel<2, 1>";
     if (kind >= PK_KERNEL_CONV_BASE && kind < PK_KERNEL_CONV_BASE + 18) {
         // names as rocprofv3 prints the template instantiation: <BM, BN, BK, WM, WN, MODE, NBUF>
         static thread_local char buf[96];
         const int k = kind - PK_KERNEL_CONV_BASE, mode = k / 6, t = (k % 6) / 2, bk = (k & 1) ? 32 : 16;
         const int bm = (t == 2) ? 64 : 128, bn = (t == 0) ? 128 : 64, wm = (t == 2) ? 32 : 64, wn = (t == 0) ? 64 : 32;
-        snprintf(buf, sizeof(buf), "conv_igemm_f32_kernel<%d, %d, %d, %d, %d, %d, 2>", bm, bn, bk, wm, wn, mode);
+        snprintf(buf, sizeof(buf), "conv_igemm_f32_kernel<%d, %d, %d, %d, %d, %d, 2, 0>", bm, bn, bk, wm, wn, mode);
         return buf;
     }
     return "?";

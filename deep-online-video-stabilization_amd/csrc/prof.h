@@ -5,7 +5,7 @@
 
 enum {
     PK_KERNEL_PAD = 1, PK_KERNEL_POOL = 2, PK_KERNEL_GAP = 3, PK_KERNEL_FC = 4, PK_KERNEL_MESH = 5,
-    PK_KERNEL_WARP = 6, PK_KERNEL_ASSEMBLE = 7, PK_KERNEL_PUSH = 8, PK_KERNEL_SPLITK_REDUCE = 9, PK_KERNEL_WGRAD = 10, PK_KERNEL_CONV_RING = 90 /* + mode */,
+    PK_KERNEL_WARP = 6, PK_KERNEL_ASSEMBLE = 7, PK_KERNEL_PUSH = 8, PK_KERNEL_SPLITK_REDUCE = 9, PK_KERNEL_WGRAD = 10, PK_KERNEL_CONV_RING = 90 /* + mode; + 3 for the bf16-operand variants */,
     PK_KERNEL_CONV_BASE = 100   // + tile*2 + (BK==32)
 };
 
