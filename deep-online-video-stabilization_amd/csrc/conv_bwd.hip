@@ -173,9 +173,26 @@ size_t wgrad_slab_floats(int Cout, int K, int M) {
     return s > 1 ? (size_t)s * Cout * K : 0;
 }
 
-// dw += sum_z slab[z] (z ascending) for every entry of the table; one float4 per thread.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ grads, const float* __restrict__ slabs,
-                                                           const WgradReduceTable t) {
+// dw += sum_z slab[0][z] (+ sum_z slab[1][z]) (z ascending, tower 0 then tower 1) for every entry of the table; one float4 per thread.
+__device__ __forceinline__ void slab_sum(const float* __restrict__ s, int splits, long elems, float4& acc) {
+    int z = 0;
+    for (; z + 3 < splits; z += 4) {                            // four slab loads in flight, added in slab order
+        const float4 v0 = *reinterpret_cast<const float4*>(s + (size_t)z * elems);
+        const float4 v1 = *reinterpret_cast<const float4*>(s + (size_t)(z + 1) * elems);
+        const float4 v2 = *reinterpret_cast<const float4*>(s + (size_t)(z + 2) * elems);
+        const float4 v3 = *reinterpret_cast<const float4*>(s + (size_t)(z + 3) * elems);
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+        acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+        acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+        acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+    }
+    for (; z < splits; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(s + (size_t)z * elems);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ grads, const WgradReduceTable t) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;          // float4 index over all entries
     if (q >= t.prefix[t.n]) return;
     int lo = 0, hi = t.n - 1;
@@ -185,32 +202,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ g
     }
     const WgradReduceEntry e = t.e[lo];
     const long i = (q - t.prefix[lo]) * 4;
-    const float* s = slabs + e.slab_off + i;
-    float4 acc = *reinterpret_cast<const float4*>(s);
-    int z = 1;
-    for (; z + 3 < e.splits; z += 4) {                          // four slab loads in flight, added in slab order
-        const float4 v0 = *reinterpret_cast<const float4*>(s + (size_t)z * e.elems);
-        const float4 v1 = *reinterpret_cast<const float4*>(s + (size_t)(z + 1) * e.elems);
-        const float4 v2 = *reinterpret_cast<const float4*>(s + (size_t)(z + 2) * e.elems);
-        const float4 v3 = *reinterpret_cast<const float4*>(s + (size_t)(z + 3) * e.elems);
-        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
-        acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
-        acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
-        acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
-    }
-    for (; z < e.splits; ++z) {
-        const float4 v = *reinterpret_cast<const float4*>(s + (size_t)z * e.elems);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    slab_sum(e.slab[0] + i, e.splits, e.elems, acc);
+    if (e.slab[1] != nullptr) slab_sum(e.slab[1] + i, e.splits, e.elems, acc);
     float4* d = reinterpret_cast<float4*>(grads + e.dw_off + i);
     float4 o = *d;
     o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
     *d = o;
 }
 
-int wgrad_reduce_flush(float* grads, const float* slabs, WgradReduceTable& t, hipStream_t st) {
+int wgrad_reduce_flush(float* grads, WgradReduceTable& t, hipStream_t st) {
     if (t.n == 0) return STABNET_OK;
-    wgrad_reduce_kernel<<<cdiv(t.prefix[t.n], 256), 256, 0, st>>>(grads, slabs, t);
+    wgrad_reduce_kernel<<<cdiv(t.prefix[t.n], 256), 256, 0, st>>>(grads, t);
     SN_LAUNCH_CHECK("wgrad_reduce_kernel");
     t.n = 0; t.prefix[0] = 0;
     return STABNET_OK;
@@ -221,7 +224,7 @@ int wgrad_reduce_flush(float* grads, const float* slabs, WgradReduceTable& t, hi
 // reduce is launched here.
 int wgrad_launch(const float* x, const float* dy, float* dw_base, long dw_off, const float* in_scale, const float* in_shift,
                  int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* slab_base,
-                 size_t* slab_cursor, WgradReduceTable* table, hipStream_t st, Prof* prof) {
+                 size_t* slab_cursor, WgradReduceTable* table, int tower, hipStream_t st, Prof* prof) {
     WgradArgs a{};
     a.x = x; a.dy = dy; a.dw = dw_base + dw_off; a.in_scale = in_scale; a.in_shift = in_shift;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
@@ -238,13 +241,18 @@ int wgrad_launch(const float* x, const float* dy, float* dw_base, long dw_off, c
         SN_REQUIRE(slab_base != nullptr && slab_cursor != nullptr, "wgrad: %d splits need a slab workspace", splits);
         a.slab = slab_base + *slab_cursor;
         WgradReduceTable* t = table ? table : &local;
-        if (t->n == WGRAD_TABLE_MAX) {
-            int rc = wgrad_reduce_flush(dw_base, slab_base, *t, st);
-            if (rc) return rc;
+        if (tower == 1 && t->n > 0 && t->e[t->n - 1].dw_off == dw_off && t->e[t->n - 1].slab[1] == nullptr &&
+            t->e[t->n - 1].splits == splits) {
+            t->e[t->n - 1].slab[1] = a.slab;                   // the second tower of the same layer joins the entry
+        } else {
+            if (t->n == WGRAD_TABLE_MAX) {
+                int rc = wgrad_reduce_flush(dw_base, *t, st);
+                if (rc) return rc;
+            }
+            t->e[t->n] = {dw_off, (long)elems, {a.slab, nullptr}, splits};
+            t->prefix[t->n + 1] = t->prefix[t->n] + (long)(elems / 4);
+            ++t->n;
         }
-        t->e[t->n] = {dw_off, (long)*slab_cursor, (long)elems, splits};
-        t->prefix[t->n + 1] = t->prefix[t->n] + (long)(elems / 4);
-        ++t->n;
         *slab_cursor += (size_t)splits * elems;
     }
     const bool rec = prof != nullptr && prof->begin(st);
@@ -252,7 +260,7 @@ int wgrad_launch(const float* x, const float* dy, float* dw_base, long dw_off, c
     if (rec) prof->end(st, PK_KERNEL_WGRAD, 2.0 * a.M * (double)a.K * Cout,
                        4.0 * ((double)a.M * Cout + (double)N * H * W * Cin + (double)a.K * Cout * splits), Cout, a.K, a.M, splits);
     SN_LAUNCH_CHECK("conv_wgrad_f32_kernel");
-    if (splits > 1 && table == nullptr) return wgrad_reduce_flush(dw_base, slab_base, local, st);
+    if (splits > 1 && table == nullptr) return wgrad_reduce_flush(dw_base, local, st);
     return STABNET_OK;
 }
 
@@ -330,7 +338,7 @@ int stabnet_conv2d_wgrad(const float* x, const float* dy, float* dw, const float
                "conv2d_wgrad: workspace too small");
     size_t cursor = 0;
     return wgrad_launch(x, dy, dw, 0, in_scale, in_shift, N, H, W, Cin, Cout, KH, KW, stride, pad,
-                        static_cast<float*>(workspace), &cursor, nullptr, (hipStream_t)stream, nullptr);
+                        static_cast<float*>(workspace), &cursor, nullptr, 0, (hipStream_t)stream, nullptr);
 }
 
 /* d conv2d / d input: dx [N,H,W,Cin] (+ residual if given) from dy [N,Ho,Wo,Cout] and the forward weights

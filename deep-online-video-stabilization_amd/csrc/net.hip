@@ -823,10 +823,10 @@ static TrainLayout train_layout(const Net* net) {
     L.T3 = take(net->max_net);
     L.fcg0 = take((size_t)net->N * 2048); L.fcg1 = take((size_t)net->N * 2048);
     size_t red = 0;
-    for (const BnInfo& b : net->bns) red = std::max(red, col_reduce_workspace_floats(b.M, b.C));
+    for (const BnInfo& b : net->bns) red = std::max(red, col_reduce_workspace_floats(b.M, b.C, 2));       // (both towers' partials)
     for (const UnitInfo& u : net->units)
-        red = std::max(red, col_reduce_workspace_floats((long)u.out.N * u.out.H * u.out.W, u.depth));
-    red = std::max(red, col_reduce_workspace_floats((long)net->t_c1.N * net->t_c1.H * net->t_c1.W, 64));
+        red = std::max(red, col_reduce_workspace_floats((long)u.out.N * u.out.H * u.out.W, u.depth, 2));
+    red = std::max(red, col_reduce_workspace_floats((long)net->t_c1.N * net->t_c1.H * net->t_c1.W, 64, 2));
     L.partial = take(red);
     L.fcpart_floats = (size_t)64 * net->N * 2048;            // fc_bwd_x partials: (Nout/32 <= 64 splits) x N x K
     L.fcpart = take(L.fcpart_floats);
@@ -864,12 +864,16 @@ static const BnInfo* find_bn(const Net* net, long chan_off) {
     return nullptr;
 }
 
-static int run_forward_train(const Net* net, float* params, const float* x, float* theta, float* ws, float eps,
-                             float decay, hipStream_t st, Prof* prof) {
+// T = 1: one tower.  T = 2: the two siamese towers (train_bundle_nobm.py:107-108, same weights) layer by layer in LOCKSTEP:
+// every convolution / pool / FC is launched for tower 0 and then for tower 1 (the weights are L2 / Infinity-Cache hot for the
+// second launch), and every batch-statistics reduction covers both towers in ONE launch (launch_*_g: these kernels are
+// launch-latency sized).  Scratch that lives for one launch only (reduction partials, split-K slabs, the re-packed dgrad
+// weights) is taken from tower 0's workspace; everything a tower keeps for its backward is in its own.
+static int run_forward_train(const Net* net, float* params, int T, const float* const* x, float* const* theta, float* const* ws,
+                             float eps, float decay, hipStream_t st, Prof* prof) {
     const TrainLayout L = train_layout(net);
-    float* scale = ws + L.bn_scale;
-    float* shift = ws + L.bn_shift;
-    float* splitk = ws + L.splitk;
+    float* splitk = ws[0] + L.splitk;
+    float* partial = ws[0] + L.partial;
     std::vector<char> have(net->bns.size(), 0);
     auto need_bn = [&](long chan_off) -> int {
         const BnInfo* b = find_bn(net, chan_off);
@@ -877,41 +881,51 @@ static int run_forward_train(const Net* net, float* params, const float* x, floa
         const size_t idx = (size_t)(b - net->bns.data());
         if (have[idx]) return STABNET_OK;
         have[idx] = 1;
-        return launch_bn_stats(ws + b->tensor_off, b->M, b->C, params + net->off_gamma + chan_off,
-                               params + net->off_beta + chan_off, eps, decay, scale + chan_off, shift + chan_off,
-                               ws + L.bn_mean + chan_off, ws + L.bn_invstd + chan_off, params + net->off_mean + chan_off,
-                               params + net->off_var + chan_off, ws + L.partial, st);
+        const float* xs[2] = {nullptr, nullptr};
+        float *sc[2], *sh[2], *mu[2], *is[2];
+        for (int t = 0; t < T; ++t) {
+            xs[t] = ws[t] + b->tensor_off;
+            sc[t] = ws[t] + L.bn_scale + chan_off; sh[t] = ws[t] + L.bn_shift + chan_off;
+            mu[t] = ws[t] + L.bn_mean + chan_off; is[t] = ws[t] + L.bn_invstd + chan_off;
+        }
+        return launch_bn_stats_g(T, xs, b->M, b->C, params + net->off_gamma + chan_off, params + net->off_beta + chan_off, eps,
+                                 decay, sc, sh, mu, is, params + net->off_mean + chan_off, params + net->off_var + chan_off,
+                                 partial, st);
     };
     for (const Step& s : net->steps) {
         int rc = STABNET_OK;
-        switch (s.kind) {
-            case S_PAD:
-                rc = launch_pad_channels(x, ws + s.out_off, (long)s.N * s.H * s.W, s.C, net->in_ch_pad, st);
-                break;
-            case S_CONV: {
-                if (s.bn_off >= 0 && (rc = need_bn(s.bn_off)) != 0) return rc;
-                ConvArgs a = s.conv;
-                a.x = ws + s.in_off; a.y = ws + s.out_off; a.w = params + s.w_off;
-                a.bias = s.b_off >= 0 ? params + s.b_off : nullptr;
-                a.residual = s.res_off >= 0 ? ws + s.res_off : nullptr;
-                a.in_scale = s.bn_off >= 0 ? scale + s.bn_off : nullptr;
-                a.in_shift = s.bn_off >= 0 ? shift + s.bn_off : nullptr;
-                a.partial = splitk;
-                rc = conv_launch(a, st, prof);
-                break;
+        if ((s.kind == S_CONV || s.kind == S_GAP) && s.bn_off >= 0 && (rc = need_bn(s.bn_off)) != 0) return rc;
+        for (int t = 0; t < T && rc == STABNET_OK; ++t) {
+            float* w = ws[t];
+            const float* scale = w + L.bn_scale;
+            const float* shift = w + L.bn_shift;
+            switch (s.kind) {
+                case S_PAD:
+                    rc = launch_pad_channels(x[t], w + s.out_off, (long)s.N * s.H * s.W, s.C, net->in_ch_pad, st);
+                    break;
+                case S_CONV: {
+                    ConvArgs a = s.conv;
+                    a.x = w + s.in_off; a.y = w + s.out_off; a.w = params + s.w_off;
+                    a.bias = s.b_off >= 0 ? params + s.b_off : nullptr;
+                    a.residual = s.res_off >= 0 ? w + s.res_off : nullptr;
+                    a.in_scale = s.bn_off >= 0 ? scale + s.bn_off : nullptr;
+                    a.in_shift = s.bn_off >= 0 ? shift + s.bn_off : nullptr;
+                    a.partial = splitk;
+                    rc = conv_launch(a, st, prof);
+                    break;
+                }
+                case S_POOL:
+                    rc = launch_max_pool_argmax(w + s.in_off, w + s.out_off, reinterpret_cast<unsigned char*>(w + L.argmax), s.N,
+                                                s.H, s.W, s.C, s.Ho, s.Wo, s.k, s.stride, s.pt, s.pl, st);
+                    break;
+                case S_GAP:
+                    rc = launch_gap_bn_relu(w + s.in_off, scale + s.bn_off, shift + s.bn_off, s.N, s.H * s.W, s.C, w + s.out_off, splitk, st);
+                    break;
+                case S_FC:
+                    rc = launch_fc(w + s.in_off, params + s.w_off, params + s.b_off,
+                                   s.out_off == EXT_OUT ? theta[t] : w + s.out_off, s.M, s.K, s.Nout, s.relu, st);
+                    break;
             }
-            case S_POOL:
-                rc = launch_max_pool_argmax(ws + s.in_off, ws + s.out_off, reinterpret_cast<unsigned char*>(ws + L.argmax), s.N,
-                                            s.H, s.W, s.C, s.Ho, s.Wo, s.k, s.stride, s.pt, s.pl, st);
-                break;
-            case S_GAP:
-                if ((rc = need_bn(s.bn_off)) != 0) return rc;
-                rc = launch_gap_bn_relu(ws + s.in_off, scale + s.bn_off, shift + s.bn_off, s.N, s.H * s.W, s.C, ws + s.out_off, splitk, st);
-                break;
-            case S_FC:
-                rc = launch_fc(ws + s.in_off, params + s.w_off, params + s.b_off,
-                               s.out_off == EXT_OUT ? theta : ws + s.out_off, s.M, s.K, s.Nout, s.relu, st);
-                break;
         }
         if (rc) return rc;
     }
@@ -931,24 +945,18 @@ static void stage_units(const Net* net, int stage, int& u_hi, int& u_lo) {      
     (void)net;
 }
 
-static int run_backward_stage(const Net* net, const float* params, const float* d_theta, float* grads, float* ws, int stage,
-                              hipStream_t st, Prof* prof) {
+static int run_backward_stage(const Net* net, const float* params, int T, const float* const* d_theta, float* grads,
+                              float* const* ws, int stage, hipStream_t st, Prof* prof) {
     const TrainLayout L = train_layout(net);
-    const float* scale = ws + L.bn_scale;
-    const float* shift = ws + L.bn_shift;
-    const float* bmean = ws + L.bn_mean;
-    const float* binv = ws + L.bn_invstd;
-    float* partial = ws + L.partial;
-    float* coef = ws + L.coef;
-    float* wt = ws + L.wt;
-    float* splitk = ws + L.splitk;
-    float* slabs = ws + L.slabs;
+    float* partial = ws[0] + L.partial;                  // (one launch at a time: shared scratch from tower 0's workspace)
+    float* wt = ws[0] + L.wt;                            // dgrad weights re-packed ONCE per step for both towers
+    float* splitk = ws[0] + L.splitk;
     const int N = net->N;
     int rc;
     SN_REQUIRE(net->units.size() == 16, "tower_bwd: unexpected unit count %zu", net->units.size());
     WgradReduceTable table{};
     // slab cursor at the start of this stage = slab floats of the stages before it (layers are visited in a fixed order)
-    size_t cursor = 0;
+    size_t cursor0 = 0;
     auto unit_slabs = [&](const UnitInfo& u) {
         size_t n = wgrad_slab_floats(u.depth, u.dbn, u.out.N * u.out.H * u.out.W) + wgrad_slab_floats(u.dbn, 9 * u.dbn, u.r2.N * u.r2.H * u.r2.W) +
                    wgrad_slab_floats(u.dbn, u.cin, u.x.N * u.x.H * u.x.W);
@@ -958,82 +966,130 @@ static int run_backward_stage(const Net* net, const float* params, const float* 
     for (int sg = 0; sg < stage; ++sg) {
         int hi, lo;
         stage_units(net, sg, hi, lo);
-        for (int ui = hi; ui >= lo; --ui) cursor += unit_slabs(net->units[ui]);
+        for (int ui = hi; ui >= lo; --ui) cursor0 += unit_slabs(net->units[ui]);
     }
-    auto wgrad = [&](const float* x, const float* dy, long w_off, const float* sc, const float* sh, int H, int W, int Cin, int Cout,
-                     int K, int stride, int pad) -> int {
-        return wgrad_launch(x, dy, grads, w_off, sc, sh, N, H, W, Cin, Cout, K, K, stride, pad, slabs, &cursor, &table, st, prof);
-    };
-    auto bn_bwd = [&](long bn, const TensorRef& xt, const float* g, const float* addend, int add_stride, float* dx) -> int {
-        return launch_bn_relu_bwd(ws + xt.off, g, scale + bn, shift + bn, bmean + bn, binv + bn, params + net->off_gamma + bn,
-                                  (long)xt.N * xt.H * xt.W, xt.C, addend, add_stride, xt.H, xt.W, grads + net->off_gamma + bn,
-                                  grads + net->off_beta + bn, dx, partial, coef, st);
-    };
-    float* GA = ws + L.GA;
-    float* GB = ws + L.GB;
-    float* T1 = ws + L.T1;
-    float* T2 = ws + L.T2;
-    float* T3 = ws + L.T3;
+    size_t cursor[2] = {cursor0, cursor0};
+    // per-tower views
+    struct TW { float* ws; const float *scale, *shift, *bmean, *binv; float *coef, *slabs, *GA, *GB, *T1, *T2, *T3; } tw[2];
     int u_hi, u_lo;
     stage_units(net, stage, u_hi, u_lo);
-    if ((15 - u_hi) & 1) std::swap(GA, GB);               // one swap per unit already processed
+    for (int t = 0; t < T; ++t) {
+        float* w = ws[t];
+        tw[t] = {w, w + L.bn_scale, w + L.bn_shift, w + L.bn_mean, w + L.bn_invstd, w + L.coef, w + L.slabs,
+                 w + L.GA, w + L.GB, w + L.T1, w + L.T2, w + L.T3};
+        if ((15 - u_hi) & 1) std::swap(tw[t].GA, tw[t].GB);            // one swap per unit already processed
+    }
+    // one wgrad launch per tower (its own slabs), joined in one table entry per layer
+    auto wgrad = [&](auto xin, auto dyin, long w_off, long bn, int H, int W, int Cin, int Cout, int K, int stride, int pad) -> int {
+        for (int t = 0; t < T; ++t) {
+            int r = wgrad_launch(xin(t), dyin(t), grads, w_off, bn >= 0 ? tw[t].scale + bn : nullptr, bn >= 0 ? tw[t].shift + bn : nullptr,
+                                 N, H, W, Cin, Cout, K, K, stride, pad, tw[t].slabs, &cursor[t], &table, t, st, prof);
+            if (r) return r;
+        }
+        return STABNET_OK;
+    };
+    // BN + ReLU backward of both towers: one reduction launch, one finalize, one apply
+    auto bn_bwd = [&](long bn, const TensorRef& xt, auto gin, auto addin, bool has_add, int add_stride, auto dxout) -> int {
+        const float *xs[2], *gs[2], *sc[2], *sh[2], *mu[2], *is[2], *ad[2];
+        float *dx[2], *cf[2];
+        for (int t = 0; t < T; ++t) {
+            xs[t] = tw[t].ws + xt.off; gs[t] = gin(t); sc[t] = tw[t].scale + bn; sh[t] = tw[t].shift + bn;
+            mu[t] = tw[t].bmean + bn; is[t] = tw[t].binv + bn; ad[t] = has_add ? addin(t) : nullptr; dx[t] = dxout(t); cf[t] = tw[t].coef;
+        }
+        return launch_bn_relu_bwd_g(T, xs, gs, sc, sh, mu, is, params + net->off_gamma + bn, (long)xt.N * xt.H * xt.W, xt.C,
+                                    has_add ? ad : nullptr, add_stride, xt.H, xt.W, grads + net->off_gamma + bn,
+                                    grads + net->off_beta + bn, dx, partial, cf, st);
+    };
+    auto bias_grad = [&](auto gin, long M, int C, long b_off) -> int {
+        const float* gs[2];
+        for (int t = 0; t < T; ++t) gs[t] = gin(t);
+        return launch_bias_grad_g(T, gs, M, C, grads + b_off, partial, st);
+    };
+    auto dgrad = [&](auto dyin, long pack_off, auto dxout, auto resin, bool has_res, int H, int W, int Cin, int Cout, int K, int stride,
+                     int pad) -> int {
+        for (int t = 0; t < T; ++t) {
+            int r = dgrad_launch(dyin(t), wt + pack_off, dxout(t), has_res ? resin(t) : nullptr, N, H, W, Cin, Cout, K, K, stride, pad,
+                                 splitk, L.splitk_bytes, st, prof);
+            if (r) return r;
+        }
+        return STABNET_OK;
+    };
+    auto GA = [&](int t) { return tw[t].GA; };
+    auto GB = [&](int t) { return tw[t].GB; };
+    auto T1 = [&](int t) { return tw[t].T1; };
+    auto T2 = [&](int t) { return tw[t].T2; };
+    auto T3 = [&](int t) { return tw[t].T3; };
+    auto cGA = [&](int t) -> const float* { return tw[t].GA; };
+    auto cT1 = [&](int t) -> const float* { return tw[t].T1; };
+    auto cT2 = [&](int t) -> const float* { return tw[t].T2; };
+    auto cT3 = [&](int t) -> const float* { return tw[t].T3; };
+    auto none = [&](int) -> const float* { return nullptr; };
+
     if (stage == 0) {
         if ((rc = pack_dgrad_weights_all(params, wt, net->packs, st)) != 0) return rc;
-        // ---- FC head (resnet.py:44-56, s_net_bundle_nobm.py:256-259)
-        float* fg[2] = {ws + L.fcg0, ws + L.fcg1};
+        // ---- FC head (resnet.py:44-56, s_net_bundle_nobm.py:256-259), tower after tower (dW += in stream order)
         const TensorRef* fin[4] = {&net->t_gap, &net->t_fc[0], &net->t_fc[1], &net->t_fc[2]};
-        const float* dy = d_theta;
-        for (int k = 3; k >= 0; --k) {
-            const float* yk = (k < 3) ? ws + net->t_fc[k].off : nullptr;            // output of layer k (ReLU mask), k < 3
-            float* dx = fg[k & 1];
-            rc = launch_fc_bwd(ws + fin[k]->off, params + net->fc_w[k], yk, dy, N, net->fc_dims[k], net->fc_dims[k + 1], k < 3,
-                               grads + net->fc_w[k], grads + net->fc_b[k], dx, ws + L.fcpart, L.fcpart_floats, st);
-            if (rc) return rc;
-            dy = dx;
-        }
-        // ---- reduce_mean + postnorm BN + ReLU
         const TensorRef& last = net->t_last;
-        if ((rc = launch_gap_bwd(dy, N, last.H * last.W, last.C, T3, st)) != 0) return rc;
-        if ((rc = bn_bwd(net->bn_post, last, T3, nullptr, 1, GA)) != 0) return rc;
+        for (int t = 0; t < T; ++t) {
+            float* w = tw[t].ws;
+            float* fg[2] = {w + L.fcg0, w + L.fcg1};
+            const float* dy = d_theta[t];
+            for (int k = 3; k >= 0; --k) {
+                const float* yk = (k < 3) ? w + net->t_fc[k].off : nullptr;         // output of layer k (ReLU mask), k < 3
+                float* dx = fg[k & 1];
+                rc = launch_fc_bwd(w + fin[k]->off, params + net->fc_w[k], yk, dy, N, net->fc_dims[k], net->fc_dims[k + 1], k < 3,
+                                   grads + net->fc_w[k], grads + net->fc_b[k], dx, w + L.fcpart, L.fcpart_floats, st);
+                if (rc) return rc;
+                dy = dx;
+            }
+            // ---- reduce_mean backward
+            if ((rc = launch_gap_bwd(dy, N, last.H * last.W, last.C, tw[t].T3, st)) != 0) return rc;
+        }
+        // ---- postnorm BN + ReLU
+        if ((rc = bn_bwd(net->bn_post, last, cT3, none, false, 1, GA)) != 0) return rc;
     }
-    // ---- bottleneck units of this stage, last to first.  G = d(unit output)
+    // ---- bottleneck units of this stage, last to first.  G = d(unit output) = GA
     for (int ui = u_hi; ui >= u_lo; --ui) {
         const UnitInfo& u = net->units[ui];
         const long Mo = (long)u.out.N * u.out.H * u.out.W;
-        float* G = GA;
+        auto X = [&](long off) { return [&, off](int t) -> const float* { return tw[t].ws + off; }; };
         // conv3 (1x1, bias) : input relu(bn2(r2))
-        if ((rc = launch_bias_grad(G, Mo, u.depth, grads + u.b3, partial, st)) != 0) return rc;
-        if ((rc = wgrad(ws + u.r2.off, G, u.w3, scale + u.bn2, shift + u.bn2, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0)) != 0) return rc;
-        if ((rc = dgrad_launch(G, wt + net->pack_w3[ui], T1, nullptr, N, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
-        if ((rc = bn_bwd(u.bn2, u.r2, T1, nullptr, 1, T1)) != 0) return rc;                      // T1 = d r2
+        if ((rc = bias_grad(cGA, Mo, u.depth, u.b3)) != 0) return rc;
+        if ((rc = wgrad(X(u.r2.off), cGA, u.w3, u.bn2, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0)) != 0) return rc;
+        if ((rc = dgrad(cGA, net->pack_w3[ui], T1, none, false, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0)) != 0) return rc;
+        if ((rc = bn_bwd(u.bn2, u.r2, cT1, none, false, 1, T1)) != 0) return rc;                       // T1 = d r2
         // conv2 (3x3, stride) : input relu(bn1(r1))
-        if ((rc = wgrad(ws + u.r1.off, T1, u.w2, scale + u.bn1, shift + u.bn1, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, u.stride, 1)) != 0) return rc;
-        if ((rc = dgrad_launch(T1, wt + net->pack_w2[ui], T2, nullptr, N, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, 3, u.stride, 1, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
-        if ((rc = bn_bwd(u.bn1, u.r1, T2, nullptr, 1, T2)) != 0) return rc;                      // T2 = d r1
+        if ((rc = wgrad(X(u.r1.off), cT1, u.w2, u.bn1, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, u.stride, 1)) != 0) return rc;
+        if ((rc = dgrad(cT1, net->pack_w2[ui], T2, none, false, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, u.stride, 1)) != 0) return rc;
+        if ((rc = bn_bwd(u.bn1, u.r1, cT2, none, false, 1, T2)) != 0) return rc;                       // T2 = d r1
         // conv1 (1x1) : input relu(bn_pre(x))
-        if ((rc = wgrad(ws + u.x.off, T2, u.w1, scale + u.bn_pre, shift + u.bn_pre, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 0)) != 0) return rc;
-        if ((rc = dgrad_launch(T2, wt + net->pack_w1[ui], T3, nullptr, N, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
+        if ((rc = wgrad(X(u.x.off), cT2, u.w1, u.bn_pre, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 0)) != 0) return rc;
+        if ((rc = dgrad(cT2, net->pack_w1[ui], T3, none, false, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 0)) != 0) return rc;
         if (u.proj) {   // projection shortcut conv1x1(preact) + bias: d preact += dgrad(G)
-            if ((rc = launch_bias_grad(G, Mo, u.depth, grads + u.b_sc, partial, st)) != 0) return rc;
-            if ((rc = wgrad(ws + u.x.off, G, u.w_sc, scale + u.bn_pre, shift + u.bn_pre, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 0)) != 0) return rc;
-            if ((rc = dgrad_launch(G, wt + net->pack_sc[ui], T3, T3, N, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 1, 0, splitk, L.splitk_bytes, st, prof)) != 0) return rc;
-            if ((rc = bn_bwd(u.bn_pre, u.x, T3, nullptr, 1, GB)) != 0) return rc;
+            if ((rc = bias_grad(cGA, Mo, u.depth, u.b_sc)) != 0) return rc;
+            if ((rc = wgrad(X(u.x.off), cGA, u.w_sc, u.bn_pre, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 0)) != 0) return rc;
+            if ((rc = dgrad(cGA, net->pack_sc[ui], T3, cT3, true, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 0)) != 0) return rc;
+            if ((rc = bn_bwd(u.bn_pre, u.x, cT3, none, false, 1, GB)) != 0) return rc;
         } else {        // identity shortcut (subsample by the unit's stride): d x += upsample(G)
-            if ((rc = bn_bwd(u.bn_pre, u.x, T3, G, u.stride, GB)) != 0) return rc;
+            if ((rc = bn_bwd(u.bn_pre, u.x, cT3, cGA, true, u.stride, GB)) != 0) return rc;
         }
-        std::swap(GA, GB);
+        for (int t = 0; t < T; ++t) std::swap(tw[t].GA, tw[t].GB);
     }
     if (stage == kNumStages - 1) {
         // ---- stem: max-pool backward, conv1 weight/bias gradient (the input needs no gradient)
         const TensorRef& c1 = net->t_c1;
         const TensorRef& pl = net->t_pool;
-        if ((rc = launch_max_pool_bwd(reinterpret_cast<const unsigned char*>(ws + L.argmax), GA, GB, N, c1.H, c1.W, c1.C, pl.H, pl.W,
-                                      3, 2, net->pool_pt, net->pool_pl, st)) != 0) return rc;
-        if ((rc = launch_bias_grad(GB, (long)N * c1.H * c1.W, 64, grads + net->b_stem, partial, st)) != 0) return rc;
-        if ((rc = wgrad(ws + net->t_xin.off, GB, net->w_stem, nullptr, nullptr, net->H, net->W, net->in_ch_pad, 64, 7, 2, 3)) != 0) return rc;
+        for (int t = 0; t < T; ++t)
+            if ((rc = launch_max_pool_bwd(reinterpret_cast<const unsigned char*>(tw[t].ws + L.argmax), tw[t].GA, tw[t].GB, N, c1.H, c1.W,
+                                          c1.C, pl.H, pl.W, 3, 2, net->pool_pt, net->pool_pl, st)) != 0) return rc;
+        auto cGB = [&](int t) -> const float* { return tw[t].GB; };
+        auto Xin = [&](int t) -> const float* { return tw[t].ws + net->t_xin.off; };
+        if ((rc = bias_grad(cGB, (long)N * c1.H * c1.W, 64, net->b_stem)) != 0) return rc;
+        if ((rc = wgrad(Xin, cGB, net->w_stem, -1, net->H, net->W, net->in_ch_pad, 64, 7, 2, 3)) != 0) return rc;
     }
-    SN_REQUIRE(cursor <= L.slab_floats, "tower_bwd: slab workspace overrun (%zu > %zu)", cursor, L.slab_floats);
-    return wgrad_reduce_flush(grads, slabs, table, st);
+    for (int t = 0; t < T; ++t)
+        SN_REQUIRE(cursor[t] <= L.slab_floats, "tower_bwd: slab workspace overrun (%zu > %zu)", cursor[t], L.slab_floats);
+    return wgrad_reduce_flush(grads, table, st);
 }
 
 extern "C" {
@@ -1055,8 +1111,27 @@ int stabnet_tower_fwd_train(const void* netp, float* params, const float* x_tens
     SN_REQUIRE(workspace_bytes >= stabnet_net_train_workspace_bytes(netp), "tower_fwd_train: workspace too small");
     if (int rc = sn_check_device(params, "tower_fwd_train: params", (hipStream_t)stream)) return rc;
     if (int rc = sn_check_device(x_tensor, "tower_fwd_train: x_tensor", (hipStream_t)stream)) return rc;
-    return run_forward_train(net, params, x_tensor, theta, static_cast<float*>(workspace), bn_eps, bn_decay,
-                             (hipStream_t)stream, static_cast<Prof*>(prof));
+    float* ws[1] = {static_cast<float*>(workspace)};
+    return run_forward_train(net, params, 1, &x_tensor, &theta, ws, bn_eps, bn_decay, (hipStream_t)stream, static_cast<Prof*>(prof));
+}
+
+/* Both siamese towers of a training step (train_bundle_nobm.py:107-108: two towers over the SAME weights) in lockstep, layer
+ * by layer: per layer the convolution of tower 1 and of tower 2 (weights cache-hot for the second), and ONE batch-statistics
+ * reduction launch covering both.  Results are those of stabnet_tower_fwd_train(x1) followed by stabnet_tower_fwd_train(x2)
+ * (the moving averages receive tower 1's update, then tower 2's).  One workspace per tower, as for the single-tower call. */
+int stabnet_towers_fwd_train(const void* netp, float* params, const float* x1, const float* x2, float* theta1, float* theta2,
+                             void* workspace1, void* workspace2, size_t workspace_bytes, float bn_eps, float bn_decay,
+                             void* stream, void* prof) {
+    const Net* net = static_cast<const Net*>(netp);
+    SN_REQUIRE(net && params && x1 && x2 && theta1 && theta2 && workspace1 && workspace2 && workspace1 != workspace2,
+               "towers_fwd_train: null pointer (or one workspace for both towers)");
+    SN_REQUIRE(net->keep_all, "towers_fwd_train: the plan must be created with keep_activations = 1");
+    SN_REQUIRE(workspace_bytes >= stabnet_net_train_workspace_bytes(netp), "towers_fwd_train: workspace too small");
+    if (int rc = sn_check_device(params, "towers_fwd_train: params", (hipStream_t)stream)) return rc;
+    const float* xs[2] = {x1, x2};
+    float* th[2] = {theta1, theta2};
+    float* ws[2] = {static_cast<float*>(workspace1), static_cast<float*>(workspace2)};
+    return run_forward_train(net, params, 2, xs, th, ws, bn_eps, bn_decay, (hipStream_t)stream, static_cast<Prof*>(prof));
 }
 
 /* Backward of the tower given d_theta [N,n_theta]; gradients are ACCUMULATED into `grads` (same layout as the
@@ -1072,9 +1147,9 @@ int stabnet_tower_bwd(const void* netp, const float* params, const float* d_thet
                       size_t workspace_bytes, void* stream, void* prof) {
     const Net* net = static_cast<const Net*>(netp);
     int rc = tower_bwd_checks(net, params, d_theta, grads, workspace, workspace_bytes, netp, stream);
+    float* ws[1] = {static_cast<float*>(workspace)};
     for (int stage = 0; rc == 0 && stage < kNumStages; ++stage)
-        rc = run_backward_stage(net, params, d_theta, grads, static_cast<float*>(workspace), stage, (hipStream_t)stream,
-                                static_cast<Prof*>(prof));
+        rc = run_backward_stage(net, params, 1, &d_theta, grads, ws, stage, (hipStream_t)stream, static_cast<Prof*>(prof));
     return rc;
 }
 /* One stage of the same backward (0: FC head + block4, 1: block3, 2: block2, 3: block1 + stem; call them in this order).
@@ -1085,8 +1160,22 @@ int stabnet_tower_bwd_stage(const void* netp, const float* params, const float* 
     int rc = tower_bwd_checks(net, params, d_theta, grads, workspace, workspace_bytes, netp, stream);
     if (rc) return rc;
     SN_REQUIRE(stage >= 0 && stage < kNumStages, "tower_bwd_stage: stage %d outside [0, %d)", stage, kNumStages);
-    return run_backward_stage(net, params, d_theta, grads, static_cast<float*>(workspace), stage, (hipStream_t)stream,
-                              static_cast<Prof*>(prof));
+    float* ws[1] = {static_cast<float*>(workspace)};
+    return run_backward_stage(net, params, 1, &d_theta, grads, ws, stage, (hipStream_t)stream, static_cast<Prof*>(prof));
+}
+/* One backward stage of BOTH towers in lockstep (see stabnet_towers_fwd_train): per layer one wgrad / dgrad launch per tower,
+ * one BN-backward reduction / finalize / apply and one bias-gradient reduction for both, the dgrad weights re-packed once,
+ * one slab reduction per stage.  After stage k the bucket stabnet_net_grad_bucket(k) holds the sum of both towers. */
+int stabnet_towers_bwd_stage(const void* netp, const float* params, const float* d_theta1, const float* d_theta2, float* grads,
+                             void* workspace1, void* workspace2, size_t workspace_bytes, int stage, void* stream, void* prof) {
+    const Net* net = static_cast<const Net*>(netp);
+    int rc = tower_bwd_checks(net, params, d_theta1, grads, workspace1, workspace_bytes, netp, stream);
+    if (rc) return rc;
+    SN_REQUIRE(d_theta2 && workspace2 && workspace2 != workspace1, "towers_bwd_stage: null pointer (or one workspace for both towers)");
+    SN_REQUIRE(stage >= 0 && stage < kNumStages, "towers_bwd_stage: stage %d outside [0, %d)", stage, kNumStages);
+    const float* dt[2] = {d_theta1, d_theta2};
+    float* ws[2] = {static_cast<float*>(workspace1), static_cast<float*>(workspace2)};
+    return run_backward_stage(net, params, 2, dt, grads, ws, stage, (hipStream_t)stream, static_cast<Prof*>(prof));
 }
 int stabnet_net_num_grad_stages(void) { return kNumStages; }
 /* Float range [lo, hi) of the gradient buffer that backward stage `stage` completes (weights and biases in network order;

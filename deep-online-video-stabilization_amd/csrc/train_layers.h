@@ -5,9 +5,21 @@
 struct Prof;
 
 size_t col_reduce_workspace_floats(long M, int C);
-int launch_bn_stats_finalize(const float* partial, int chunks, long M, int C, const float* gamma, const float* beta, float eps,
-                             float decay, float* scale, float* shift, float* save_mean, float* save_invstd, float* mov_mean,
-                             float* mov_var, hipStream_t st);
+size_t col_reduce_workspace_floats(long M, int C, int groups);
+// per-tower operands of the grouped (both siamese towers in one launch) reduction / BN kernels
+struct ColGroups { const float* x[2]; const float* g[2]; const float* scale[2]; const float* shift[2]; const float* mean[2]; const float* invstd[2]; };
+struct BnStatOut { float* scale[2]; float* shift[2]; float* save_mean[2]; float* save_invstd[2]; };
+struct BnBwdFin { const float* invstd[2]; float* coef[2]; };
+struct BnApply { const float* x[2]; const float* g[2]; const float* scale[2]; const float* shift[2]; const float* mean[2];
+                 const float* invstd[2]; const float* coef[2]; const float* addend[2]; float* d_x[2]; };
+int launch_bn_stats_g(int groups, const float* const* x, long M, int C, const float* gamma, const float* beta, float eps,
+                      float decay, float* const* scale, float* const* shift, float* const* save_mean, float* const* save_invstd,
+                      float* mov_mean, float* mov_var, float* partial, hipStream_t st);
+int launch_bn_relu_bwd_g(int groups, const float* const* x, const float* const* g, const float* const* scale,
+                         const float* const* shift, const float* const* mean, const float* const* invstd, const float* gamma,
+                         long M, int C, const float* const* addend, int add_stride, int H, int W, float* d_gamma, float* d_beta,
+                         float* const* d_x, float* partial, float* const* coef, hipStream_t st);
+int launch_bias_grad_g(int groups, const float* const* g, long M, int C, float* d_bias, float* partial, hipStream_t st);
 int launch_bn_stats(const float* x, long M, int C, const float* gamma, const float* beta, float eps, float decay,
                     float* scale, float* shift, float* save_mean, float* save_invstd, float* mov_mean, float* mov_var,
                     float* partial, hipStream_t st);
@@ -29,14 +41,16 @@ int launch_adam(float* w, const float* g, const float* g2, float* m, float* v, l
 
 // wgrad: per-split partial slabs reduced in split order by wgrad_reduce_flush (conv_bwd.hip)
 #define WGRAD_TABLE_MAX 64
-struct WgradReduceEntry { long dw_off, slab_off, elems; int splits; };
+struct WgradReduceEntry { long dw_off, elems; const float* slab[2]; int splits; };   // slab[t]: tower t's [splits][elems] partials (or null)
 struct WgradReduceTable { WgradReduceEntry e[WGRAD_TABLE_MAX]; long prefix[WGRAD_TABLE_MAX + 1]; int n; };
 int wgrad_splits(int Cout, int K, int M, int* rows_per_split);
 size_t wgrad_slab_floats(int Cout, int K, int M);
-int wgrad_reduce_flush(float* grads, const float* slabs, WgradReduceTable& t, hipStream_t st);
+int wgrad_reduce_flush(float* grads, WgradReduceTable& t, hipStream_t st);
+// tower: 0 / 1 -- with two towers in lockstep the same layer's second launch joins the first one's table entry, and the
+// reduce adds tower 0's slabs, then tower 1's, then accumulates into dw (one writer per element)
 int wgrad_launch(const float* x, const float* dy, float* dw_base, long dw_off, const float* in_scale, const float* in_shift,
                  int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* slab_base,
-                 size_t* slab_cursor, WgradReduceTable* table, hipStream_t st, Prof* prof);
+                 size_t* slab_cursor, WgradReduceTable* table, int tower, hipStream_t st, Prof* prof);
 int pack_dgrad_weights(const float* w, float* wt, int Cout, int KH, int KW, int Cin, hipStream_t st);
 // every dgrad weight tensor of a net, re-packed by one launch: layer i = params[w_off ...] OHWI [Cout][K][K][Cin] ->
 // wt[prefix[i] ...] as [Cin][K][K][Cout] with both filter axes flipped

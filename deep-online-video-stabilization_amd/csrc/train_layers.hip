@@ -14,13 +14,22 @@
 //   MODE 0: (sum x, sum x^2)                           BN batch statistics
 //   MODE 1: (sum dz, sum dz*xhat), dz = g*(a>0)        BN+ReLU backward;  a = x*scale+shift, xhat = (x-mean)*invstd
 //   MODE 2: (sum g, -)                                 bias gradient
-// block = 16 channel-quads x 16 row lanes; grid = (C/64, chunks); partial [chunks][2][C].
+// block = 16 channel-quads x 16 row lanes; grid = (C/64, chunks, groups); partial [groups][chunks][2][C].
+// GROUPS: the two siamese towers run in lockstep (train_bundle_nobm.py:107-108 builds two towers over the same weights), so
+// the same reduction of both towers is ONE launch (blockIdx.z = tower) -- these kernels are launch-latency sized (about 6 us
+// for either one or two towers' rows), and there are ~240 of them per tower per step.
 template <int MODE>
-__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                         long M, int C, long rows_per_chunk, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void col_reduce_kernel(const ColGroups G, long M, int C, long rows_per_chunk,
+                                                         float* __restrict__ partial_all) {
     __shared__ float4 s0[16][16], s1[16][16];
+    const int grp = blockIdx.z;
+    const float* __restrict__ x = G.x[grp];
+    const float* __restrict__ g = G.g[grp];
+    const float* __restrict__ scale = G.scale[grp];
+    const float* __restrict__ shift = G.shift[grp];
+    const float* __restrict__ mean = G.mean[grp];
+    const float* __restrict__ invstd = G.invstd[grp];
+    float* __restrict__ partial = partial_all + (size_t)grp * gridDim.y * 2 * C;
     const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 64 + q * 4;
     const long r0 = (long)blockIdx.y * rows_per_chunk;
@@ -89,65 +98,81 @@ __device__ __forceinline__ void combine_partials(const float* __restrict__ parti
 }
 
 // BN statistics finalize: batch mean / biased variance (float64 combine) -> folded (scale, shift), saved (mean, invstd),
-// moving averages.  grid = C/64 blocks of 256 threads.
-__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __restrict__ partial, int chunks, long M, int C,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                float eps, float decay, float* __restrict__ scale,
-                                                                float* __restrict__ shift, float* __restrict__ save_mean,
-                                                                float* __restrict__ save_invstd, float* __restrict__ mov_mean,
+// moving averages.  grid = C/64 blocks of 1024 threads.  Groups (towers) are finalized one after the other by the same
+// thread, so the moving averages receive tower 1's update and then tower 2's, as two sequential steps would give.
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __restrict__ partial, int chunks, int groups, long M,
+                                                                int C, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps, float decay,
+                                                                const BnStatOut o, float* __restrict__ mov_mean,
                                                                 float* __restrict__ mov_var) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
-    double s, ss;
-    combine_partials(partial, chunks, C, c, lane, s, ss);
-    if (lane != 0 || c >= C) return;
-    const double mean = s / (double)M;
-    const double var = fmax(ss / (double)M - mean * mean, 0.0);
-    const float meanf = (float)mean, varf = (float)var;
-    const float is = 1.0f / sqrtf(varf + eps);
-    const float inv = is * gamma[c];
-    scale[c] = inv;
-    shift[c] = beta[c] - meanf * inv;
-    save_mean[c] = meanf;
-    save_invstd[c] = is;
-    if (mov_mean != nullptr) {
-        mov_mean[c] -= (mov_mean[c] - meanf) * (1.0f - decay);
-        mov_var[c] -= (mov_var[c] - varf) * (1.0f - decay);
+    for (int gi = 0; gi < groups; ++gi) {
+        double s, ss;
+        combine_partials(partial + (size_t)gi * chunks * 2 * C, chunks, C, c, lane, s, ss);
+        if (lane == 0 && c < C) {
+            const double mean = s / (double)M;
+            const double var = fmax(ss / (double)M - mean * mean, 0.0);
+            const float meanf = (float)mean, varf = (float)var;
+            const float is = 1.0f / sqrtf(varf + eps);
+            const float inv = is * gamma[c];
+            o.scale[gi][c] = inv;
+            o.shift[gi][c] = beta[c] - meanf * inv;
+            o.save_mean[gi][c] = meanf;
+            o.save_invstd[gi][c] = is;
+            if (mov_mean != nullptr) {
+                mov_mean[c] -= (mov_mean[c] - meanf) * (1.0f - decay);
+                mov_var[c] -= (mov_var[c] - varf) * (1.0f - decay);
+            }
+        }
+        __syncthreads();                                  // combine_partials' LDS is reused by the next group
     }
 }
 
-// BN backward finalize: d_gamma += sum dz*xhat, d_beta += sum dz; coefficients for the apply pass:
-// coef[0][c] = gamma*invstd, coef[1][c] = mean(dz), coef[2][c] = mean(dz*xhat).
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, long M, int C,
-                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                                              float* __restrict__ d_gamma, float* __restrict__ d_beta,
-                                                              float* __restrict__ coef) {
+// BN backward finalize: d_gamma += sum dz*xhat, d_beta += sum dz (group after group, fixed order); coefficients for the apply
+// pass per group: coef[0][c] = gamma*invstd, coef[1][c] = mean(dz), coef[2][c] = mean(dz*xhat).
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int groups, long M,
+                                                              int C, const float* __restrict__ gamma, const BnBwdFin f,
+                                                              float* __restrict__ d_gamma, float* __restrict__ d_beta) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
-    double s, sx;
-    combine_partials(partial, chunks, C, c, lane, s, sx);
-    if (lane != 0 || c >= C) return;
-    d_beta[c] += (float)s;
-    d_gamma[c] += (float)sx;
-    coef[c] = gamma[c] * invstd[c];
-    coef[C + c] = (float)(s / (double)M);
-    coef[2 * C + c] = (float)(sx / (double)M);
+    for (int gi = 0; gi < groups; ++gi) {
+        double s, sx;
+        combine_partials(partial + (size_t)gi * chunks * 2 * C, chunks, C, c, lane, s, sx);
+        if (lane == 0 && c < C) {
+            d_beta[c] += (float)s;
+            d_gamma[c] += (float)sx;
+            float* coef = f.coef[gi];
+            coef[c] = gamma[c] * f.invstd[gi][c];
+            coef[C + c] = (float)(s / (double)M);
+            coef[2 * C + c] = (float)(sx / (double)M);
+        }
+        __syncthreads();
+    }
 }
 
-__global__ __launch_bounds__(1024) void bias_grad_finalize_kernel(const float* __restrict__ partial, int chunks, int C,
+__global__ __launch_bounds__(1024) void bias_grad_finalize_kernel(const float* __restrict__ partial, int chunks, int groups, int C,
                                                                  float* __restrict__ d_bias) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
-    double s, unused;
-    combine_partials(partial, chunks, C, c, lane, s, unused);
-    if (lane != 0 || c >= C) return;
-    d_bias[c] += (float)s;
+    for (int gi = 0; gi < groups; ++gi) {
+        double s, unused;
+        combine_partials(partial + (size_t)gi * chunks * 2 * C, chunks, C, c, lane, s, unused);
+        if (lane == 0 && c < C) d_bias[c] += (float)s;
+        __syncthreads();
+    }
 }
 
 // d_x = k1 * (dz - c1 - xhat * c2)  (+ addend[n, y/s, x/s, c] where y%s == 0 and x%s == 0: the identity-shortcut branch).
 // g may alias d_x (in-place).  One thread per float4.
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* g,
-                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ coef, const float* __restrict__ addend,
-                                                           int add_stride, int H, int W, long M, int C, float* d_x) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnApply A, int add_stride, int H, int W, long M, int C) {
+    const int grp = blockIdx.y;
+    const float* __restrict__ x = A.x[grp];
+    const float* g = A.g[grp];
+    const float* __restrict__ scale = A.scale[grp];
+    const float* __restrict__ shift = A.shift[grp];
+    const float* __restrict__ mean = A.mean[grp];
+    const float* __restrict__ invstd = A.invstd[grp];
+    const float* __restrict__ coef = A.coef[grp];
+    const float* __restrict__ addend = A.addend[grp];
+    float* d_x = A.d_x[grp];
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const int c4n = C / 4;
     if (i >= M * c4n) return;
@@ -394,53 +419,84 @@ size_t col_reduce_workspace_floats(long M, int C) {
     return (size_t)chunks * 2 * C;
 }
 
-// statistics from partial rows [chunks][2][C] (written by col_reduce_kernel<0> or by the convolution epilogue)
-int launch_bn_stats_finalize(const float* partial, int chunks, long M, int C, const float* gamma, const float* beta, float eps,
-                             float decay, float* scale, float* shift, float* save_mean, float* save_invstd, float* mov_mean,
-                             float* mov_var, hipStream_t st) {
-    bn_stats_finalize_kernel<<<cdiv(C, 64), 64 * FIN_LANES, 0, st>>>(partial, chunks, M, C, gamma, beta, eps, decay, scale, shift,
-                                                                     save_mean, save_invstd, mov_mean, mov_var);
+size_t col_reduce_workspace_floats(long M, int C, int groups) { return (size_t)groups * col_reduce_workspace_floats(M, C); }
+
+// ---- grouped launchers: groups = 1 (one tower) or 2 (both siamese towers in one launch each) --------------------------
+int launch_bn_stats_g(int groups, const float* const* x, long M, int C, const float* gamma, const float* beta, float eps,
+                      float decay, float* const* scale, float* const* shift, float* const* save_mean, float* const* save_invstd,
+                      float* mov_mean, float* mov_var, float* partial, hipStream_t st) {
+    SN_REQUIRE(C % 4 == 0 && (groups == 1 || groups == 2), "bn_stats: C %% 4 != 0 or bad group count");
+    long rpc;
+    const int chunks = reduce_chunks(M, C, rpc);
+    ColGroups G{};
+    BnStatOut o{};
+    for (int i = 0; i < groups; ++i) {
+        G.x[i] = x[i];
+        o.scale[i] = scale[i]; o.shift[i] = shift[i]; o.save_mean[i] = save_mean[i]; o.save_invstd[i] = save_invstd[i];
+    }
+    col_reduce_kernel<0><<<dim3(cdiv(C, 64), chunks, groups), 256, 0, st>>>(G, M, C, rpc, partial);
+    SN_LAUNCH_CHECK("col_reduce_kernel<0>");
+    bn_stats_finalize_kernel<<<cdiv(C, 64), 64 * FIN_LANES, 0, st>>>(partial, chunks, groups, M, C, gamma, beta, eps, decay, o,
+                                                                     mov_mean, mov_var);
     SN_LAUNCH_CHECK("bn_stats_finalize_kernel");
     return STABNET_OK;
 }
 
+int launch_bn_relu_bwd_g(int groups, const float* const* x, const float* const* g, const float* const* scale,
+                         const float* const* shift, const float* const* mean, const float* const* invstd, const float* gamma,
+                         long M, int C, const float* const* addend, int add_stride, int H, int W, float* d_gamma, float* d_beta,
+                         float* const* d_x, float* partial, float* const* coef, hipStream_t st) {
+    SN_REQUIRE(C % 4 == 0 && (groups == 1 || groups == 2), "bn_bwd: C %% 4 != 0 or bad group count");
+    long rpc;
+    const int chunks = reduce_chunks(M, C, rpc);
+    ColGroups G{};
+    BnBwdFin f{};
+    BnApply A{};
+    for (int i = 0; i < groups; ++i) {
+        G.x[i] = x[i]; G.g[i] = g[i]; G.scale[i] = scale[i]; G.shift[i] = shift[i]; G.mean[i] = mean[i]; G.invstd[i] = invstd[i];
+        f.invstd[i] = invstd[i]; f.coef[i] = coef[i];
+        A.x[i] = x[i]; A.g[i] = g[i]; A.scale[i] = scale[i]; A.shift[i] = shift[i]; A.mean[i] = mean[i]; A.invstd[i] = invstd[i];
+        A.coef[i] = coef[i]; A.addend[i] = addend ? addend[i] : nullptr; A.d_x[i] = d_x[i];
+    }
+    col_reduce_kernel<1><<<dim3(cdiv(C, 64), chunks, groups), 256, 0, st>>>(G, M, C, rpc, partial);
+    SN_LAUNCH_CHECK("col_reduce_kernel<1>");
+    bn_bwd_finalize_kernel<<<cdiv(C, 64), 64 * FIN_LANES, 0, st>>>(partial, chunks, groups, M, C, gamma, f, d_gamma, d_beta);
+    SN_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+    bn_bwd_apply_kernel<<<dim3(cdiv(M * (C / 4), 256), groups), 256, 0, st>>>(A, add_stride, H, W, M, C);
+    SN_LAUNCH_CHECK("bn_bwd_apply_kernel");
+    return STABNET_OK;
+}
+
+int launch_bias_grad_g(int groups, const float* const* g, long M, int C, float* d_bias, float* partial, hipStream_t st) {
+    SN_REQUIRE(C % 4 == 0 && (groups == 1 || groups == 2), "bias_grad: C %% 4 != 0 or bad group count");
+    long rpc;
+    const int chunks = reduce_chunks(M, C, rpc);
+    ColGroups G{};
+    for (int i = 0; i < groups; ++i) G.g[i] = g[i];
+    col_reduce_kernel<2><<<dim3(cdiv(C, 64), chunks, groups), 256, 0, st>>>(G, M, C, rpc, partial);
+    SN_LAUNCH_CHECK("col_reduce_kernel<2>");
+    bias_grad_finalize_kernel<<<cdiv(C, 64), 64 * FIN_LANES, 0, st>>>(partial, chunks, groups, C, d_bias);
+    SN_LAUNCH_CHECK("bias_grad_finalize_kernel");
+    return STABNET_OK;
+}
+
+// ---- single-tower forms
 int launch_bn_stats(const float* x, long M, int C, const float* gamma, const float* beta, float eps, float decay,
                     float* scale, float* shift, float* save_mean, float* save_invstd, float* mov_mean, float* mov_var,
                     float* partial, hipStream_t st) {
-    SN_REQUIRE(C % 4 == 0, "bn_stats: C %% 4 != 0");
-    long rpc;
-    const int chunks = reduce_chunks(M, C, rpc);
-    col_reduce_kernel<0><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, rpc, partial);
-    SN_LAUNCH_CHECK("col_reduce_kernel<0>");
-    return launch_bn_stats_finalize(partial, chunks, M, C, gamma, beta, eps, decay, scale, shift, save_mean, save_invstd, mov_mean,
-                                    mov_var, st);
+    return launch_bn_stats_g(1, &x, M, C, gamma, beta, eps, decay, &scale, &shift, &save_mean, &save_invstd, mov_mean, mov_var,
+                             partial, st);
 }
 
 int launch_bn_relu_bwd(const float* x, const float* g, const float* scale, const float* shift, const float* mean,
                        const float* invstd, const float* gamma, long M, int C, const float* addend, int add_stride, int H,
                        int W, float* d_gamma, float* d_beta, float* d_x, float* partial, float* coef, hipStream_t st) {
-    SN_REQUIRE(C % 4 == 0, "bn_bwd: C %% 4 != 0");
-    long rpc;
-    const int chunks = reduce_chunks(M, C, rpc);
-    col_reduce_kernel<1><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(x, g, scale, shift, mean, invstd, M, C, rpc, partial);
-    SN_LAUNCH_CHECK("col_reduce_kernel<1>");
-    bn_bwd_finalize_kernel<<<cdiv(C, 64), 64 * FIN_LANES, 0, st>>>(partial, chunks, M, C, gamma, invstd, d_gamma, d_beta, coef);
-    SN_LAUNCH_CHECK("bn_bwd_finalize_kernel");
-    bn_bwd_apply_kernel<<<cdiv(M * (C / 4), 256), 256, 0, st>>>(x, g, scale, shift, mean, invstd, coef, addend, add_stride, H,
-                                                                W, M, C, d_x);
-    SN_LAUNCH_CHECK("bn_bwd_apply_kernel");
-    return STABNET_OK;
+    return launch_bn_relu_bwd_g(1, &x, &g, &scale, &shift, &mean, &invstd, gamma, M, C, addend ? &addend : nullptr, add_stride, H, W,
+                                d_gamma, d_beta, &d_x, partial, &coef, st);
 }
 
 int launch_bias_grad(const float* g, long M, int C, float* d_bias, float* partial, hipStream_t st) {
-    SN_REQUIRE(C % 4 == 0, "bias_grad: C %% 4 != 0");
-    long rpc;
-    const int chunks = reduce_chunks(M, C, rpc);
-    col_reduce_kernel<2><<<dim3(cdiv(C, 64), chunks), 256, 0, st>>>(nullptr, g, nullptr, nullptr, nullptr, nullptr, M, C, rpc, partial);
-    SN_LAUNCH_CHECK("col_reduce_kernel<2>");
-    bias_grad_finalize_kernel<<<cdiv(C, 64), 64 * FIN_LANES, 0, st>>>(partial, chunks, C, d_bias);
-    SN_LAUNCH_CHECK("bias_grad_finalize_kernel");
-    return STABNET_OK;
+    return launch_bias_grad_g(1, &g, M, C, d_bias, partial, st);
 }
 
 int launch_max_pool_bwd(const unsigned char* argmax, const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo,

@@ -2,8 +2,9 @@
 weights, the temporal loss through the flow sampler, the loss schedule gates, Adam with the staircase learning rate,
 and -- new, the reference is single-device -- data parallelism: one process per GPU, samples sharded across
 ranks, local BN statistics, ONE 121.6 MB gradient per step (both towers accumulate into the same buffer) all-reduced over
-RCCL (torch.distributed "nccl") in reverse layer order: tower 1's backward runs in four stages (FC head + block4, block3,
-block2, block1 + stem) and each stage's parameter bucket goes to the communication stream as soon as that stage is
+RCCL (torch.distributed "nccl") in reverse layer order: the two towers run layer by layer in LOCKSTEP (one launch per
+batch-statistics reduction for both, dgrad weights packed once), their backward in four stages (FC head + block4, block3,
+block2, block1 + stem), and each stage's parameter bucket goes to the communication stream as soon as that stage is
 enqueued, so the collective of the big late layers overlaps the backward of the early ones.
 Every tensor op is a C-ABI kernel; torch allocates, holds pointers, owns the streams and the collective.  The step is
 reproducible bit for bit (no order-dependent float atomics anywhere on the path)."""
@@ -94,25 +95,26 @@ class Trainer:
         self.compute_done = []                # bench: one event per step on the compute stream, just before the join
 
     # ------------------------------------------------------------------------------------------------------
-    def _tower_fwd(self, k: int, x):
-        _lib.call("stabnet_tower_fwd_train", self.plan.handle, ptr(self.params), ptr(x), ptr(self.theta[k]),
-                  ptr(self.ws[k]), self.ws_bytes, self.cfg.bn_eps, self.cfg.bn_decay, stream_ptr(self.device),
-                  self.prof.handle if self.prof is not None else 0, device=self.device)
-        return self.theta[k]
+    def _towers_fwd(self, x1, x2):
+        """Both siamese towers layer by layer in lockstep (one batch-statistics reduction launch per layer for both)."""
+        _lib.call("stabnet_towers_fwd_train", self.plan.handle, ptr(self.params), ptr(x1), ptr(x2), ptr(self.theta[0]),
+                  ptr(self.theta[1]), ptr(self.ws[0]), ptr(self.ws[1]), self.ws_bytes, self.cfg.bn_eps, self.cfg.bn_decay,
+                  stream_ptr(self.device), self.prof.handle if self.prof is not None else 0, device=self.device)
+        return self.theta
 
-    def _tower_bwd(self, k: int, d_theta, reduce_buckets: bool = False):
-        """Backward of tower k into the shared gradient buffer.  reduce_buckets (the LAST tower, world > 1): stage by stage,
-        with each finished bucket handed to the communication stream (reverse layer order, overlapping what is left)."""
+    def _towers_bwd(self, d_theta1, d_theta2):
+        """Backward of both towers in lockstep into the ONE gradient buffer, stage by stage (FC head + block4, block3, block2,
+        block1 + stem); with world > 1 each finished bucket is handed to the communication stream (reverse layer order), so
+        the collective of the big late layers overlaps the backward of the early ones."""
         prof = self.prof.handle if self.prof is not None else 0
-        if not (reduce_buckets and self.world > 1):
-            _lib.call("stabnet_tower_bwd", self.plan.handle, ptr(self.params), ptr(d_theta), ptr(self.grads),
-                      ptr(self.ws[k]), self.ws_bytes, stream_ptr(self.device), prof, device=self.device)
-            return
         for stage in range(self.n_stages):
-            _lib.call("stabnet_tower_bwd_stage", self.plan.handle, ptr(self.params), ptr(d_theta), ptr(self.grads),
-                      ptr(self.ws[k]), self.ws_bytes, stage, stream_ptr(self.device), prof, device=self.device)
-            self._allreduce_async(*self.buckets[stage])
-        self._allreduce_async(*self.bn_bucket)
+            _lib.call("stabnet_towers_bwd_stage", self.plan.handle, ptr(self.params), ptr(d_theta1), ptr(d_theta2),
+                      ptr(self.grads), ptr(self.ws[0]), ptr(self.ws[1]), self.ws_bytes, stage, stream_ptr(self.device), prof,
+                      device=self.device)
+            if self.world > 1:
+                self._allreduce_async(*self.buckets[stage])
+        if self.world > 1:
+            self._allreduce_async(*self.bn_bucket)
 
     def _allreduce_async(self, lo: int, hi: int):
         """Sum grads[lo:hi] over ranks on the communication stream, ordered after everything enqueued so far."""
@@ -144,9 +146,10 @@ class Trainer:
         self.grads.zero_()
         self.regu_val.zero_()
         towers = []
-        for k, s in enumerate(("1", "2")):
-            x = dev_f32(batch["x" + s])
-            theta = self._tower_fwd(k, x)
+        xs = [dev_f32(batch["x1"]), dev_f32(batch["x2"])]
+        thetas = self._towers_fwd(xs[0], xs[1])
+        for k in (0, 1):
+            x, theta = xs[k], thetas[k]
             frame = warp.slice_channel(x, cur)                                    # x = x_tensor[..., 12:13], s_net:281
             r = warp.warp_from_theta(frame, theta, cfg)
             r["frame"] = frame
@@ -173,11 +176,11 @@ class Trainer:
         _, g_o2w = train_ops.masked_mse_grad(towers[0]["output"], o2w, towers[0]["black_pix"], nb2w, t_sums, c_tmp,
                                              ga=g_out[0], accumulate_a=True, want_gb=True)
         train_ops.interp_bwd(fx, fy, g_o2w, d_im=g_out[1])
-        # ---- through the warp and the mesh losses to d theta, then the towers: tower 2 first (plain accumulation), then
-        # tower 1 stage by stage with the finished buckets going to the collective
+        # ---- through the warp and the mesh losses to d theta of both towers, then the joint staged backward
         w_id = cfg.theta_mul + cfg.grid_theta_mul
         mesh = [None, None]
-        for k in (1, 0):
+        d_thetas = [None, None]
+        for k in (0, 1):
             t = towers[k]
             d_pts2 = train_ops.transformer_bwd(t["pts2"], t["Hs"], t["frame"], t["x_map"], t["y_map"], g_out[k],
                                                feats[k][1], feats[k][2], cfg, dmap_scale=feats[k][4])
@@ -185,7 +188,8 @@ class Trainer:
                                                      live * cfg.consistency_mul, float(g["use_black_loss"]),
                                                      live * cfg.black_mul)
             mesh[k] = losses4
-            self._tower_bwd(k, d_theta, reduce_buckets=(k == 0))
+            d_thetas[k] = d_theta
+        self._towers_bwd(d_thetas[0], d_thetas[1])
         if self.world > 1:
             if self.comm_timing is not None:          # bench: when did backward itself finish (vs the last bucket's end)?
                 ev = torch.cuda.Event(enable_timing=True)

@@ -244,6 +244,13 @@ size_t stabnet_net_train_workspace_bytes(const void* net);
 int stabnet_tower_fwd_train(const void* net, float* params, const float* x_tensor, float* theta, void* workspace,
                             size_t workspace_bytes, float bn_eps, float bn_decay, void* stream, void* prof);
 
+/* Both siamese towers of a step (train_bundle_nobm.py:107-108: two towers over the same weights) in LOCKSTEP, layer by layer:
+ * per layer the convolution of tower 1 and of tower 2, and ONE batch-statistics reduction launch covering both (those kernels
+ * are launch-latency sized).  Same results as tower_fwd_train(x1) then tower_fwd_train(x2); one workspace per tower. */
+int stabnet_towers_fwd_train(const void* net, float* params, const float* x1, const float* x2, float* theta1, float* theta2,
+                             void* workspace1, void* workspace2, size_t workspace_bytes, float bn_eps, float bn_decay,
+                             void* stream, void* prof);
+
 /* Backward from d_theta [N,n_theta]; parameter gradients are ACCUMULATED into grads (layout = trainable prefix of
  * params; zero once per step). */
 int stabnet_tower_bwd(const void* net, const float* params, const float* d_theta, float* grads, void* workspace,
@@ -254,6 +261,10 @@ int stabnet_tower_bwd(const void* net, const float* params, const float* d_theta
  * backward (reverse layer order).  The BN gamma / beta sections (stabnet_net_bn_grad_range) are final after the last stage. */
 int stabnet_tower_bwd_stage(const void* net, const float* params, const float* d_theta, float* grads, void* workspace,
                             size_t workspace_bytes, int stage, void* stream, void* prof);
+/* One backward stage of BOTH towers in lockstep (after stabnet_towers_fwd_train): the bucket of stage k then holds the sum of
+ * both towers' gradients.  The dgrad weights are re-packed once, the wgrad slabs of both towers are reduced together. */
+int stabnet_towers_bwd_stage(const void* net, const float* params, const float* d_theta1, const float* d_theta2, float* grads,
+                             void* workspace1, void* workspace2, size_t workspace_bytes, int stage, void* stream, void* prof);
 int stabnet_net_num_grad_stages(void);
 int stabnet_net_grad_bucket(const void* net, int stage, long* lo, long* hi);
 int stabnet_net_bn_grad_range(const void* net, long* lo, long* hi);
