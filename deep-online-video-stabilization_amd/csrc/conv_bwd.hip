@@ -23,6 +23,11 @@ typedef float f32x16w __attribute__((ext_vector_type(16)));
 struct WgradArgs {
     const float* x;          // forward input NHWC [N,H,W,Cin]
     const float* dy;         // output gradient NHWC [N,Ho,Wo,Cout]
+    const float* x2;         // second siamese tower (or null): blockIdx.z >= splits_per_tower works on (x2, dy2, in_scale2,
+    const float* dy2;        //   in_shift2) -- one launch per layer for both towers, slabs [tower][split]
+    const float* in_scale2;
+    const float* in_shift2;
+    int splits_per_tower;
     float* dw;               // OHWI [Cout][KH][KW][Cin], accumulated into (only when slab == nullptr: one split)
     float* slab;             // [splits][Cout][K] partial sums, or nullptr
     const float* in_scale;   // forward prologue (folded BN + ReLU) or null
@@ -37,7 +42,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs p) 
     __shared__ __attribute__((aligned(16))) float sA[2][BR][BT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * BT, k0 = blockIdx.y * BT;
-    const int m_begin = blockIdx.z * p.rows_per_split;
+    const int tower = (int)blockIdx.z >= p.splits_per_tower ? 1 : 0;
+    const int zsplit = (int)blockIdx.z - tower * p.splits_per_tower;
+    const float* __restrict__ px = tower ? p.x2 : p.x;
+    const float* __restrict__ pdy = tower ? p.dy2 : p.dy;
+    const float* __restrict__ pscale = tower ? p.in_scale2 : p.in_scale;
+    const float* __restrict__ pshift = tower ? p.in_shift2 : p.in_shift;
+    const int m_begin = zsplit * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
     if (m_begin >= m_end) return;
 
@@ -51,10 +62,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs p) 
     const int ncol = n0 + lq * 4;
     const bool n_ok = ncol < p.Cout;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool has_pro = p.in_scale != nullptr;
+    const bool has_pro = pscale != nullptr;
     if (has_pro && k_ok) {
-        sc = *reinterpret_cast<const float4*>(p.in_scale + c_t);
-        sh = *reinterpret_cast<const float4*>(p.in_shift + c_t);
+        sc = *reinterpret_cast<const float4*>(pscale + c_t);
+        sh = *reinterpret_cast<const float4*>(pshift + c_t);
     }
     // pixel coordinates of the two rows this thread loads, advanced incrementally by BR per step
     int img[2], oy[2], ox[2];
@@ -79,8 +90,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs p) 
             const bool a_ok = row_ok && k_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const unsigned yoff = (row_ok && n_ok) ? (unsigned)(m * p.Cout + ncol) : 0u;
             const unsigned aoff = a_ok ? (unsigned)(((img[t] * p.H + iy) * p.W + ix) * p.Cin + c_t) : 0u;
-            ry[t] = *reinterpret_cast<const float4*>(p.dy + yoff);
-            ra[t] = *reinterpret_cast<const float4*>(p.x + aoff);
+            ry[t] = *reinterpret_cast<const float4*>(pdy + yoff);
+            ra[t] = *reinterpret_cast<const float4*>(px + aoff);
             ok |= ((row_ok && n_ok) ? 1u : 0u) << (2 * t);
             ok |= (a_ok ? 2u : 0u) << (2 * t);
             // advance this row by BR pixels
@@ -168,8 +179,9 @@ int wgrad_splits(int Cout, int K, int M, int* rows_per_split) {
     if (rows_per_split) *rows_per_split = rps;
     return cdiv(M, rps);
 }
-size_t wgrad_slab_floats(int Cout, int K, int M) {
-    const int s = wgrad_splits(Cout, K, M, nullptr);
+// slab floats one launch over T towers needs (none when a single block owns every element: T * splits == 1)
+size_t wgrad_slab_floats(int Cout, int K, int M, int T) {
+    const int s = T * wgrad_splits(Cout, K, M, nullptr);
     return s > 1 ? (size_t)s * Cout * K : 0;
 }
 
@@ -219,49 +231,58 @@ int wgrad_reduce_flush(float* grads, WgradReduceTable& t, hipStream_t st) {
     return STABNET_OK;
 }
 
-// dw_base + dw_off: where the gradient accumulates.  slab_base + *slab_cursor: this layer's slabs (the cursor advances);
-// the entry is appended to `table` and reduced by the next wgrad_reduce_flush.  table == nullptr (stand-alone use): the
-// reduce is launched here.
-int wgrad_launch(const float* x, const float* dy, float* dw_base, long dw_off, const float* in_scale, const float* in_shift,
-                 int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* slab_base,
-                 size_t* slab_cursor, WgradReduceTable* table, int tower, hipStream_t st, Prof* prof) {
+// dw_base + dw_off: where the gradient accumulates.  T = 1 or 2 towers (x[t], dy[t], in_scale[t], in_shift[t]): ONE launch,
+// grid.z = T * splits, slabs [tower][split] at slab_base + *slab_cursor (the cursor advances); the entry is appended to
+// `table` and reduced (tower 0's splits, then tower 1's) by the next wgrad_reduce_flush.  table == nullptr (stand-alone use):
+// the reduce is launched here.
+int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* dw_base, long dw_off, const float* const* in_scale,
+                   const float* const* in_shift, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                   float* slab_base, size_t* slab_cursor, size_t slab_capacity, WgradReduceTable* table, hipStream_t st, Prof* prof) {
     WgradArgs a{};
-    a.x = x; a.dy = dy; a.dw = dw_base + dw_off; a.in_scale = in_scale; a.in_shift = in_shift;
+    a.x = x[0]; a.dy = dy[0]; a.dw = dw_base + dw_off; a.in_scale = in_scale ? in_scale[0] : nullptr; a.in_shift = in_shift ? in_shift[0] : nullptr;
+    if (T == 2) { a.x2 = x[1]; a.dy2 = dy[1]; a.in_scale2 = in_scale ? in_scale[1] : nullptr; a.in_shift2 = in_shift ? in_shift[1] : nullptr; }
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.Ho = (H + 2 * pad - KH) / stride + 1;
     a.Wo = (W + 2 * pad - KW) / stride + 1;
     a.M = N * a.Ho * a.Wo;
     a.K = KH * KW * Cin;
+    SN_REQUIRE(T == 1 || T == 2, "wgrad: 1 or 2 towers");
     SN_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "wgrad: channel counts must be multiples of 4");
     SN_REQUIRE((long)a.M * Cout < (1L << 31) && (long)N * H * W * Cin < (1L << 31), "wgrad: tensors must have < 2^31 elements");
     const int splits = wgrad_splits(Cout, a.K, a.M, &a.rows_per_split);
+    a.splits_per_tower = splits;
+    const int total = T * splits;
     const size_t elems = (size_t)Cout * a.K;
     WgradReduceTable local{};
-    if (splits > 1) {
-        SN_REQUIRE(slab_base != nullptr && slab_cursor != nullptr, "wgrad: %d splits need a slab workspace", splits);
+    if (total > 1) {
+        SN_REQUIRE(slab_base != nullptr && slab_cursor != nullptr, "wgrad: %d splits need a slab workspace", total);
+        SN_REQUIRE(*slab_cursor + (size_t)total * elems <= slab_capacity, "wgrad: slab workspace overrun (%zu + %zu > %zu floats)",
+                   *slab_cursor, (size_t)total * elems, slab_capacity);          // checked BEFORE anything is written
         a.slab = slab_base + *slab_cursor;
         WgradReduceTable* t = table ? table : &local;
-        if (tower == 1 && t->n > 0 && t->e[t->n - 1].dw_off == dw_off && t->e[t->n - 1].slab[1] == nullptr &&
-            t->e[t->n - 1].splits == splits) {
-            t->e[t->n - 1].slab[1] = a.slab;                   // the second tower of the same layer joins the entry
-        } else {
-            if (t->n == WGRAD_TABLE_MAX) {
-                int rc = wgrad_reduce_flush(dw_base, *t, st);
-                if (rc) return rc;
-            }
-            t->e[t->n] = {dw_off, (long)elems, {a.slab, nullptr}, splits};
-            t->prefix[t->n + 1] = t->prefix[t->n] + (long)(elems / 4);
-            ++t->n;
+        if (t->n == WGRAD_TABLE_MAX) {
+            int rc = wgrad_reduce_flush(dw_base, *t, st);
+            if (rc) return rc;
         }
-        *slab_cursor += (size_t)splits * elems;
+        t->e[t->n] = {dw_off, (long)elems, {a.slab, nullptr}, total};
+        t->prefix[t->n + 1] = t->prefix[t->n] + (long)(elems / 4);
+        ++t->n;
+        *slab_cursor += (size_t)total * elems;
     }
     const bool rec = prof != nullptr && prof->begin(st);
-    conv_wgrad_f32_kernel<<<dim3(cdiv(Cout, 64), cdiv(a.K, 64), splits), 256, 0, st>>>(a);
-    if (rec) prof->end(st, PK_KERNEL_WGRAD, 2.0 * a.M * (double)a.K * Cout,
-                       4.0 * ((double)a.M * Cout + (double)N * H * W * Cin + (double)a.K * Cout * splits), Cout, a.K, a.M, splits);
+    conv_wgrad_f32_kernel<<<dim3(cdiv(Cout, 64), cdiv(a.K, 64), total), 256, 0, st>>>(a);
+    if (rec) prof->end(st, PK_KERNEL_WGRAD, 2.0 * T * a.M * (double)a.K * Cout,
+                       4.0 * T * ((double)a.M * Cout + (double)N * H * W * Cin + (double)a.K * Cout * splits), Cout, a.K, T * a.M, total);
     SN_LAUNCH_CHECK("conv_wgrad_f32_kernel");
-    if (splits > 1 && table == nullptr) return wgrad_reduce_flush(dw_base, local, st);
+    if (total > 1 && table == nullptr) return wgrad_reduce_flush(dw_base, local, st);
     return STABNET_OK;
+}
+
+int wgrad_launch(const float* x, const float* dy, float* dw_base, long dw_off, const float* in_scale, const float* in_shift,
+                 int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* slab_base,
+                 size_t* slab_cursor, size_t slab_capacity, WgradReduceTable* table, hipStream_t st, Prof* prof) {
+    return wgrad_launch_g(1, &x, &dy, dw_base, dw_off, in_scale ? &in_scale : nullptr, in_shift ? &in_shift : nullptr, N, H, W, Cin,
+                          Cout, KH, KW, stride, pad, slab_base, slab_cursor, slab_capacity, table, st, prof);
 }
 
 // All dgrad weight tensors of a net in ONE launch (the per-layer version cost 104 launches of ~6 us per training step).
@@ -327,7 +348,7 @@ extern "C" {
  * workspace: stabnet_conv2d_wgrad_workspace_bytes() (per-split partial slabs; reduced in split order: reproducible). */
 size_t stabnet_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    return wgrad_slab_floats(Cout, KH * KW * Cin, N * Ho * Wo) * sizeof(float) + 16;
+    return wgrad_slab_floats(Cout, KH * KW * Cin, N * Ho * Wo, 1) * sizeof(float) + 16;
 }
 int stabnet_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* in_scale, const float* in_shift,
                          int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,
@@ -338,7 +359,7 @@ int stabnet_conv2d_wgrad(const float* x, const float* dy, float* dw, const float
                "conv2d_wgrad: workspace too small");
     size_t cursor = 0;
     return wgrad_launch(x, dy, dw, 0, in_scale, in_shift, N, H, W, Cin, Cout, KH, KW, stride, pad,
-                        static_cast<float*>(workspace), &cursor, nullptr, 0, (hipStream_t)stream, nullptr);
+                        static_cast<float*>(workspace), &cursor, workspace_bytes / sizeof(float), nullptr, (hipStream_t)stream, nullptr);
 }
 
 /* d conv2d / d input: dx [N,H,W,Cin] (+ residual if given) from dy [N,Ho,Wo,Cout] and the forward weights

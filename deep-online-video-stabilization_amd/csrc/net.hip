@@ -814,6 +814,25 @@ static ConvArgs dgrad_args(int N, int H, int W, int Cin, int Cout, int KH, int s
     return a;
 }
 
+// slab floats the wgrad launches of backward stages [s0, s1) need for T towers (stage order: see run_backward_stage)
+static const int kNumStagesFwd = 4;
+static size_t unit_slab_floats(const UnitInfo& u, int T) {
+    size_t n = wgrad_slab_floats(u.depth, u.dbn, u.out.N * u.out.H * u.out.W, T) + wgrad_slab_floats(u.dbn, 9 * u.dbn, u.r2.N * u.r2.H * u.r2.W, T) +
+               wgrad_slab_floats(u.dbn, u.cin, u.x.N * u.x.H * u.x.W, T);
+    if (u.proj) n += wgrad_slab_floats(u.depth, u.cin, u.x.N * u.x.H * u.x.W, T);
+    return n;
+}
+static size_t net_slab_floats(const Net* net, int T, int s0, int s1) {
+    const int first[5] = {0, 3, 7, 13, 16};               // units of block 1..4 (resnet_v2_50: 3, 4, 6, 3)
+    size_t n = 0;
+    for (int sg = s0; sg < s1; ++sg) {
+        const int blk = 3 - sg;
+        for (int ui = first[blk + 1] - 1; ui >= first[blk] && ui < (int)net->units.size(); --ui) n += unit_slab_floats(net->units[ui], T);
+        if (sg == kNumStagesFwd - 1) n += wgrad_slab_floats(64, 49 * net->in_ch_pad, net->t_c1.N * net->t_c1.H * net->t_c1.W, T);
+    }
+    return n;
+}
+
 static TrainLayout train_layout(const Net* net) {
     TrainLayout L{};
     size_t o = rnd64(net->act_floats);
@@ -843,17 +862,10 @@ static TrainLayout train_layout(const Net* net) {
     }
     L.splitk_bytes = sk;
     L.splitk = take(sk / sizeof(float) + 64);
-    // wgrad partial slabs of every conv of one backward (consumed stage by stage by wgrad_reduce_flush)
-    size_t sl = 0;
-    for (const UnitInfo& u : net->units) {
-        sl += wgrad_slab_floats(u.depth, u.dbn, u.out.N * u.out.H * u.out.W);
-        sl += wgrad_slab_floats(u.dbn, 9 * u.dbn, u.r2.N * u.r2.H * u.r2.W);
-        sl += wgrad_slab_floats(u.dbn, u.cin, u.x.N * u.x.H * u.x.W);
-        if (u.proj) sl += wgrad_slab_floats(u.depth, u.cin, u.x.N * u.x.H * u.x.W);
-    }
-    sl += wgrad_slab_floats(64, 49 * net->in_ch_pad, net->t_c1.N * net->t_c1.H * net->t_c1.W);
-    L.slab_floats = sl;
-    L.slabs = take(sl + 64);
+    // wgrad partial slabs of every conv of one backward (consumed stage by stage by wgrad_reduce_flush); sized for the lockstep
+    // backward of both towers (their slabs of a layer are contiguous, in tower 0's workspace)
+    L.slab_floats = net_slab_floats(net, 2, 0, kNumStagesFwd);
+    L.slabs = take(L.slab_floats + 64);
     L.total = o;
     return L;
 }
@@ -956,19 +968,7 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
     SN_REQUIRE(net->units.size() == 16, "tower_bwd: unexpected unit count %zu", net->units.size());
     WgradReduceTable table{};
     // slab cursor at the start of this stage = slab floats of the stages before it (layers are visited in a fixed order)
-    size_t cursor0 = 0;
-    auto unit_slabs = [&](const UnitInfo& u) {
-        size_t n = wgrad_slab_floats(u.depth, u.dbn, u.out.N * u.out.H * u.out.W) + wgrad_slab_floats(u.dbn, 9 * u.dbn, u.r2.N * u.r2.H * u.r2.W) +
-                   wgrad_slab_floats(u.dbn, u.cin, u.x.N * u.x.H * u.x.W);
-        if (u.proj) n += wgrad_slab_floats(u.depth, u.cin, u.x.N * u.x.H * u.x.W);
-        return n;
-    };
-    for (int sg = 0; sg < stage; ++sg) {
-        int hi, lo;
-        stage_units(net, sg, hi, lo);
-        for (int ui = hi; ui >= lo; --ui) cursor0 += unit_slabs(net->units[ui]);
-    }
-    size_t cursor[2] = {cursor0, cursor0};
+    size_t cursor = net_slab_floats(net, T, 0, stage);
     // per-tower views
     struct TW { float* ws; const float *scale, *shift, *bmean, *binv; float *coef, *slabs, *GA, *GB, *T1, *T2, *T3; } tw[2];
     int u_hi, u_lo;
@@ -979,14 +979,15 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
                  w + L.GA, w + L.GB, w + L.T1, w + L.T2, w + L.T3};
         if ((15 - u_hi) & 1) std::swap(tw[t].GA, tw[t].GB);            // one swap per unit already processed
     }
-    // one wgrad launch per tower (its own slabs), joined in one table entry per layer
+    // ONE wgrad launch per layer for both towers (grid.z = tower x split), slabs [tower][split] in tower 0's workspace
     auto wgrad = [&](auto xin, auto dyin, long w_off, long bn, int H, int W, int Cin, int Cout, int K, int stride, int pad) -> int {
+        const float *xs[2], *dys[2], *sc[2], *sh[2];
         for (int t = 0; t < T; ++t) {
-            int r = wgrad_launch(xin(t), dyin(t), grads, w_off, bn >= 0 ? tw[t].scale + bn : nullptr, bn >= 0 ? tw[t].shift + bn : nullptr,
-                                 N, H, W, Cin, Cout, K, K, stride, pad, tw[t].slabs, &cursor[t], &table, t, st, prof);
-            if (r) return r;
+            xs[t] = xin(t); dys[t] = dyin(t);
+            sc[t] = bn >= 0 ? tw[t].scale + bn : nullptr; sh[t] = bn >= 0 ? tw[t].shift + bn : nullptr;
         }
-        return STABNET_OK;
+        return wgrad_launch_g(T, xs, dys, grads, w_off, bn >= 0 ? sc : nullptr, bn >= 0 ? sh : nullptr, N, H, W, Cin, Cout, K, K, stride,
+                              pad, tw[0].slabs, &cursor, L.slab_floats, &table, st, prof);
     };
     // BN + ReLU backward of both towers: one reduction launch, one finalize, one apply
     auto bn_bwd = [&](long bn, const TensorRef& xt, auto gin, auto addin, bool has_add, int add_stride, auto dxout) -> int {
@@ -1087,8 +1088,6 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
         if ((rc = bias_grad(cGB, (long)N * c1.H * c1.W, 64, net->b_stem)) != 0) return rc;
         if ((rc = wgrad(Xin, cGB, net->w_stem, -1, net->H, net->W, net->in_ch_pad, 64, 7, 2, 3)) != 0) return rc;
     }
-    for (int t = 0; t < T; ++t)
-        SN_REQUIRE(cursor[t] <= L.slab_floats, "tower_bwd: slab workspace overrun (%zu > %zu)", cursor[t], L.slab_floats);
     return wgrad_reduce_flush(grads, table, st);
 }
 

@@ -44,13 +44,15 @@ int launch_adam(float* w, const float* g, const float* g2, float* m, float* v, l
 struct WgradReduceEntry { long dw_off, elems; const float* slab[2]; int splits; };   // slab[t]: tower t's [splits][elems] partials (or null)
 struct WgradReduceTable { WgradReduceEntry e[WGRAD_TABLE_MAX]; long prefix[WGRAD_TABLE_MAX + 1]; int n; };
 int wgrad_splits(int Cout, int K, int M, int* rows_per_split);
-size_t wgrad_slab_floats(int Cout, int K, int M);
+size_t wgrad_slab_floats(int Cout, int K, int M, int T);
 int wgrad_reduce_flush(float* grads, WgradReduceTable& t, hipStream_t st);
-// tower: 0 / 1 -- with two towers in lockstep the same layer's second launch joins the first one's table entry, and the
-// reduce adds tower 0's slabs, then tower 1's, then accumulates into dw (one writer per element)
+// T towers (1 or 2) in ONE launch: grid.z = T * splits, slabs [tower][split]; the reduce adds them in that order into dw
+int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* dw_base, long dw_off, const float* const* in_scale,
+                   const float* const* in_shift, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                   float* slab_base, size_t* slab_cursor, size_t slab_capacity, WgradReduceTable* table, hipStream_t st, Prof* prof);
 int wgrad_launch(const float* x, const float* dy, float* dw_base, long dw_off, const float* in_scale, const float* in_shift,
                  int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* slab_base,
-                 size_t* slab_cursor, WgradReduceTable* table, int tower, hipStream_t st, Prof* prof);
+                 size_t* slab_cursor, size_t slab_capacity, WgradReduceTable* table, hipStream_t st, Prof* prof);
 int pack_dgrad_weights(const float* w, float* wt, int Cout, int KH, int KW, int Cin, hipStream_t st);
 // every dgrad weight tensor of a net, re-packed by one launch: layer i = params[w_off ...] OHWI [Cout][K][K][Cin] ->
 // wt[prefix[i] ...] as [Cin][K][K][Cout] with both filter axes flipped

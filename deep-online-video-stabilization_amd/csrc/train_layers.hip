@@ -76,36 +76,37 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const ColGroups G, long
     }
 }
 
-// Sum of the chunk partials for 64 channels per block: 16 lanes per channel walk the chunks (float64), fixed-order combine
-// through LDS (deterministic).  Returns the two sums in lane 0 of each channel.  Blocks are 64 x 16 = 1024 threads: the
-// conv-epilogue statistics come as one partial row per 32 pixels (thousands of chunks for the block1 tensors).
-constexpr int FIN_LANES = 16;
+// Sum of the chunk partials for FIN_CH channels per block: FIN_LANES lanes per channel walk the chunks (float64), fixed-order
+// combine through LDS (deterministic).  Returns the two sums in lane 0 of each channel.  These kernels are latency bound (a
+// handful of blocks, each lane a serial chain of L2-latency loads): 16 channels x 64 lanes per 1024-thread block keeps the
+// chain at chunks / 64 iterations (was 64 channels x 16 lanes: 9.9 us for two towers' 512 chunks, now a third of that).
+constexpr int FIN_LANES = 64, FIN_CH = 16;
 __device__ __forceinline__ void combine_partials(const float* __restrict__ partial, int chunks, int C, int c, int lane,
                                                  double& s0, double& s1) {
-    __shared__ double sh0[FIN_LANES][64], sh1[FIN_LANES][64];
+    __shared__ double sh0[FIN_LANES][FIN_CH], sh1[FIN_LANES][FIN_CH];
     double a0 = 0.0, a1 = 0.0;
     if (c < C)
         for (int k = lane; k < chunks; k += FIN_LANES) {
             a0 += (double)partial[(size_t)k * 2 * C + c];
             a1 += (double)partial[(size_t)k * 2 * C + C + c];
         }
-    sh0[lane][threadIdx.x & 63] = a0;
-    sh1[lane][threadIdx.x & 63] = a1;
+    const int t = threadIdx.x % FIN_CH;
+    sh0[lane][t] = a0;
+    sh1[lane][t] = a1;
     __syncthreads();
-    const int t = threadIdx.x & 63;
     s0 = sh0[0][t]; s1 = sh1[0][t];
     for (int i = 1; i < FIN_LANES; ++i) { s0 += sh0[i][t]; s1 += sh1[i][t]; }
 }
 
 // BN statistics finalize: batch mean / biased variance (float64 combine) -> folded (scale, shift), saved (mean, invstd),
-// moving averages.  grid = C/64 blocks of 1024 threads.  Groups (towers) are finalized one after the other by the same
+// moving averages.  grid = C/16 blocks of 1024 threads.  Groups (towers) are finalized one after the other by the same
 // thread, so the moving averages receive tower 1's update and then tower 2's, as two sequential steps would give.
 __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __restrict__ partial, int chunks, int groups, long M,
                                                                 int C, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float eps, float decay,
                                                                 const BnStatOut o, float* __restrict__ mov_mean,
                                                                 float* __restrict__ mov_var) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH), lane = threadIdx.x / FIN_CH;
     for (int gi = 0; gi < groups; ++gi) {
         double s, ss;
         combine_partials(partial + (size_t)gi * chunks * 2 * C, chunks, C, c, lane, s, ss);
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int groups, long M,
                                                               int C, const float* __restrict__ gamma, const BnBwdFin f,
                                                               float* __restrict__ d_gamma, float* __restrict__ d_beta) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH), lane = threadIdx.x / FIN_CH;
     for (int gi = 0; gi < groups; ++gi) {
         double s, sx;
         combine_partials(partial + (size_t)gi * chunks * 2 * C, chunks, C, c, lane, s, sx);
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 
 __global__ __launch_bounds__(1024) void bias_grad_finalize_kernel(const float* __restrict__ partial, int chunks, int groups, int C,
                                                                  float* __restrict__ d_bias) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH), lane = threadIdx.x / FIN_CH;
     for (int gi = 0; gi < groups; ++gi) {
         double s, unused;
         combine_partials(partial + (size_t)gi * chunks * 2 * C, chunks, C, c, lane, s, unused);
@@ -436,7 +437,7 @@ int launch_bn_stats_g(int groups, const float* const* x, long M, int C, const fl
     }
     col_reduce_kernel<0><<<dim3(cdiv(C, 64), chunks, groups), 256, 0, st>>>(G, M, C, rpc, partial);
     SN_LAUNCH_CHECK("col_reduce_kernel<0>");
-    bn_stats_finalize_kernel<<<cdiv(C, 64), 64 * FIN_LANES, 0, st>>>(partial, chunks, groups, M, C, gamma, beta, eps, decay, o,
+    bn_stats_finalize_kernel<<<cdiv(C, FIN_CH), FIN_CH * FIN_LANES, 0, st>>>(partial, chunks, groups, M, C, gamma, beta, eps, decay, o,
                                                                      mov_mean, mov_var);
     SN_LAUNCH_CHECK("bn_stats_finalize_kernel");
     return STABNET_OK;
@@ -460,7 +461,7 @@ int launch_bn_relu_bwd_g(int groups, const float* const* x, const float* const* 
     }
     col_reduce_kernel<1><<<dim3(cdiv(C, 64), chunks, groups), 256, 0, st>>>(G, M, C, rpc, partial);
     SN_LAUNCH_CHECK("col_reduce_kernel<1>");
-    bn_bwd_finalize_kernel<<<cdiv(C, 64), 64 * FIN_LANES, 0, st>>>(partial, chunks, groups, M, C, gamma, f, d_gamma, d_beta);
+    bn_bwd_finalize_kernel<<<cdiv(C, FIN_CH), FIN_CH * FIN_LANES, 0, st>>>(partial, chunks, groups, M, C, gamma, f, d_gamma, d_beta);
     SN_LAUNCH_CHECK("bn_bwd_finalize_kernel");
     bn_bwd_apply_kernel<<<dim3(cdiv(M * (C / 4), 256), groups), 256, 0, st>>>(A, add_stride, H, W, M, C);
     SN_LAUNCH_CHECK("bn_bwd_apply_kernel");
@@ -475,7 +476,7 @@ int launch_bias_grad_g(int groups, const float* const* g, long M, int C, float* 
     for (int i = 0; i < groups; ++i) G.g[i] = g[i];
     col_reduce_kernel<2><<<dim3(cdiv(C, 64), chunks, groups), 256, 0, st>>>(G, M, C, rpc, partial);
     SN_LAUNCH_CHECK("col_reduce_kernel<2>");
-    bias_grad_finalize_kernel<<<cdiv(C, 64), 64 * FIN_LANES, 0, st>>>(partial, chunks, groups, C, d_bias);
+    bias_grad_finalize_kernel<<<cdiv(C, FIN_CH), FIN_CH * FIN_LANES, 0, st>>>(partial, chunks, groups, C, d_bias);
     SN_LAUNCH_CHECK("bias_grad_finalize_kernel");
     return STABNET_OK;
 }
