@@ -114,7 +114,8 @@ def main():
     params = load_weights(args, cfg)
     dev = torch.device(args.device)
     torch.cuda.set_device(dev)
-    stream = StabNetStream(params, H, W, cfg, streams=1, device=dev, refine=args.refine, before_ch=args.before_ch)
+    stream = StabNetStream(params, H, W, cfg, streams=1, device=dev, refine=args.refine, before_ch=args.before_ch,
+                           use_graph=True)            # one frame = 75 fixed-argument launches: captured once, replayed per frame
     stream.track_black()            # all_black += round(black) inside every refine pass (deploy_bundle.py:234,291), on the device
 
     clips = []
