@@ -1,9 +1,10 @@
 """GPU parity AT THE BASELINE.json SIZES:
   configs[0]  256x256 clip, 64 frames, seed 1234    -> StabNetStream vs the committed oracle trajectory + per-frame checksums
-  configs[1]  1280x720, batch 1                     -> one deploy_step (ring -> regressor -> warp -> feedback) vs the oracle
+  configs[1]  1280x720, batch 1                     -> deploy_step (ring -> regressor -> warp -> feedback) vs the oracle
+  configs[4]  1920x1080 (per-GPU shape)             -> one deploy_step vs the oracle
   configs[2]  training, 8 pairs at 288x512          -> forward losses vs the NumPy oracle (training=True) and the full-step
                                                        gradient of every parameter tensor vs float64 autograd
-(configs[3] needs 8 GPUs; configs[4] = test_fullsize_gpu.py::test_stream_at_1080p_*.)"""
+(configs[3] and the 8-stream form of configs[4] need 8 GPUs; one stream per GPU is what each of them runs.)"""
 import os
 import zlib
 
@@ -33,19 +34,20 @@ def _lipschitz_pixel_check(src, got_out, ref, got_xm, got_ym, H, W):
     assert (err <= bound)[~border].all(), "max excess %g" % float((err - bound)[~border].max())
 
 
-def test_deploy_step_720p_matches_oracle(cuda):
-    """configs[1]: the timed call of deploy_bundle.py:286 at 1280x720, through the on-device ring."""
+@pytest.mark.parametrize("H,W,frames", [(720, 1280, (1, 2)), (1080, 1920, (1,))])
+def test_deploy_step_matches_oracle_at_size(cuda, H, W, frames):
+    """configs[1] (1280x720) and the per-GPU shape of configs[4] (1920x1080): the timed call of deploy_bundle.py:286 through
+    the on-device ring, against the oracle."""
     from stabnet_amd import synthetic, warp
     from stabnet_amd.config import Config
     from stabnet_amd.deploy import StabNetStream
-    H, W = 720, 1280
     cfg, ocfg = Config(height=H, width=W), O.Config(height=H, width=W)
     P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
     clip = synthetic.make_clip(H, W, 3, seed=1234)
     s = StabNetStream(P, H, W, cfg, streams=1, device=cuda)
     s.start(torch.from_numpy(clip[0:1]).to(cuda))
     ring = O.DeployRing(clip[0], ocfg)
-    for t in (1, 2):                                        # frame 2 sees frame 1's fed-back output at lag 1
+    for t in frames:                                        # (720p) frame 2 sees frame 1's fed-back output at lag 1
         got = s.step(torch.from_numpy(clip[t:t + 1]).to(cuda))
         torch.cuda.synchronize()
         ref, frame = O.deploy_step(ring, clip[t], P, ocfg)
