@@ -838,8 +838,10 @@ static TrainLayout train_layout(const Net* net) {
     size_t o = rnd64(net->act_floats);
     auto take = [&](size_t n) { const size_t r = o; o += rnd64(n); return r; };
     L.bn_scale = take(net->G); L.bn_shift = take(net->G); L.bn_mean = take(net->G); L.bn_invstd = take(net->G);
-    L.GA = take(net->max_net); L.GB = take(net->max_net); L.T1 = take(net->max_r); L.T2 = take(net->max_r);
-    L.T3 = take(net->max_net);
+    // gradient scratch of the backward: sized for BOTH towers -- in the lockstep backward tower 1's copy of a tensor of `sz` floats
+    // sits right behind tower 0's (buf + sz), so the pair is one [2N,...] tensor and every dgrad is ONE launch over 2N samples
+    L.GA = take(2 * net->max_net); L.GB = take(2 * net->max_net); L.T1 = take(2 * net->max_r); L.T2 = take(2 * net->max_r);
+    L.T3 = take(2 * net->max_net);
     L.fcg0 = take((size_t)net->N * 2048); L.fcg1 = take((size_t)net->N * 2048);
     size_t red = 0;
     for (const BnInfo& b : net->bns) red = std::max(red, col_reduce_workspace_floats(b.M, b.C, 2));       // (both towers' partials)
@@ -854,11 +856,13 @@ static TrainLayout train_layout(const Net* net) {
     L.argmax = take((net->t_pool.size + 3) / 4);              // one byte per pooled element
     size_t sk = net->splitk_bytes;
     for (const UnitInfo& u : net->units) {
-        ConvArgs a3 = dgrad_args(u.r2.N, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0);
-        ConvArgs a2 = dgrad_args(u.r1.N, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, u.stride, 1);
-        ConvArgs a1 = dgrad_args(u.x.N, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 0);
-        ConvArgs as = dgrad_args(u.x.N, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 0);
-        sk = std::max({sk, conv_plan(a3), conv_plan(a2), conv_plan(a1), u.proj ? conv_plan(as) : (size_t)0});
+        for (int T = 1; T <= 2; ++T) {                        // one tower, or both towers as one [2N,...] tensor
+            ConvArgs a3 = dgrad_args(T * u.r2.N, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0);
+            ConvArgs a2 = dgrad_args(T * u.r1.N, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, u.stride, 1);
+            ConvArgs a1 = dgrad_args(T * u.x.N, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 0);
+            ConvArgs as = dgrad_args(T * u.x.N, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 0);
+            sk = std::max({sk, conv_plan(a3), conv_plan(a2), conv_plan(a1), u.proj ? conv_plan(as) : (size_t)0});
+        }
     }
     L.splitk_bytes = sk;
     L.splitk = take(sk / sizeof(float) + 64);
@@ -969,16 +973,19 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
     WgradReduceTable table{};
     // slab cursor at the start of this stage = slab floats of the stages before it (layers are visited in a fixed order)
     size_t cursor = net_slab_floats(net, T, 0, stage);
-    // per-tower views
-    struct TW { float* ws; const float *scale, *shift, *bmean, *binv; float *coef, *slabs, *GA, *GB, *T1, *T2, *T3; } tw[2];
+    // per-tower views.  The gradient scratch (GA, GB, T1, T2, T3) lives in tower 0's workspace for both towers: tower t's copy
+    // of a tensor of `sz` floats is at buf + t * sz, i.e. the pair is ONE [T*N, ...] tensor and a dgrad is one launch over it.
+    struct TW { float* ws; const float *scale, *shift, *bmean, *binv; float *coef, *slabs; } tw[2];
     int u_hi, u_lo;
     stage_units(net, stage, u_hi, u_lo);
     for (int t = 0; t < T; ++t) {
         float* w = ws[t];
-        tw[t] = {w, w + L.bn_scale, w + L.bn_shift, w + L.bn_mean, w + L.bn_invstd, w + L.coef, w + L.slabs,
-                 w + L.GA, w + L.GB, w + L.T1, w + L.T2, w + L.T3};
-        if ((15 - u_hi) & 1) std::swap(tw[t].GA, tw[t].GB);            // one swap per unit already processed
+        tw[t] = {w, w + L.bn_scale, w + L.bn_shift, w + L.bn_mean, w + L.bn_invstd, w + L.coef, w + L.slabs};
     }
+    float *bGA = ws[0] + L.GA, *bGB = ws[0] + L.GB, *bT1 = ws[0] + L.T1, *bT2 = ws[0] + L.T2, *bT3 = ws[0] + L.T3;
+    if ((15 - u_hi) & 1) std::swap(bGA, bGB);                          // one swap per unit already processed
+    auto V = [](float* buf, size_t sz) { return [buf, sz](int t) -> float* { return buf + (size_t)t * sz; }; };
+    auto CV = [](const float* buf, size_t sz) { return [buf, sz](int t) -> const float* { return buf + (size_t)t * sz; }; };
     // ONE wgrad launch per layer for both towers (grid.z = tower x split), slabs [tower][split] in tower 0's workspace
     auto wgrad = [&](auto xin, auto dyin, long w_off, long bn, int H, int W, int Cin, int Cout, int K, int stride, int pad) -> int {
         const float *xs[2], *dys[2], *sc[2], *sh[2];
@@ -1006,24 +1013,11 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
         for (int t = 0; t < T; ++t) gs[t] = gin(t);
         return launch_bias_grad_g(T, gs, M, C, grads + b_off, partial, st);
     };
-    auto dgrad = [&](auto dyin, long pack_off, auto dxout, auto resin, bool has_res, int H, int W, int Cin, int Cout, int K, int stride,
+    // dgrad of both towers: ONE launch over the [T*N, ...] pair (dy, dx, residual are pair bases)
+    auto dgrad = [&](const float* dy, long pack_off, float* dx, const float* res, int H, int W, int Cin, int Cout, int K, int stride,
                      int pad) -> int {
-        for (int t = 0; t < T; ++t) {
-            int r = dgrad_launch(dyin(t), wt + pack_off, dxout(t), has_res ? resin(t) : nullptr, N, H, W, Cin, Cout, K, K, stride, pad,
-                                 splitk, L.splitk_bytes, st, prof);
-            if (r) return r;
-        }
-        return STABNET_OK;
+        return dgrad_launch(dy, wt + pack_off, dx, res, T * N, H, W, Cin, Cout, K, K, stride, pad, splitk, L.splitk_bytes, st, prof);
     };
-    auto GA = [&](int t) { return tw[t].GA; };
-    auto GB = [&](int t) { return tw[t].GB; };
-    auto T1 = [&](int t) { return tw[t].T1; };
-    auto T2 = [&](int t) { return tw[t].T2; };
-    auto T3 = [&](int t) { return tw[t].T3; };
-    auto cGA = [&](int t) -> const float* { return tw[t].GA; };
-    auto cT1 = [&](int t) -> const float* { return tw[t].T1; };
-    auto cT2 = [&](int t) -> const float* { return tw[t].T2; };
-    auto cT3 = [&](int t) -> const float* { return tw[t].T3; };
     auto none = [&](int) -> const float* { return nullptr; };
 
     if (stage == 0) {
@@ -1044,49 +1038,50 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
                 dy = dx;
             }
             // ---- reduce_mean backward
-            if ((rc = launch_gap_bwd(dy, N, last.H * last.W, last.C, tw[t].T3, st)) != 0) return rc;
+            if ((rc = launch_gap_bwd(dy, N, last.H * last.W, last.C, bT3 + (size_t)t * last.size, st)) != 0) return rc;
         }
         // ---- postnorm BN + ReLU
-        if ((rc = bn_bwd(net->bn_post, last, cT3, none, false, 1, GA)) != 0) return rc;
+        if ((rc = bn_bwd(net->bn_post, last, CV(bT3, last.size), none, false, 1, V(bGA, last.size))) != 0) return rc;
     }
     // ---- bottleneck units of this stage, last to first.  G = d(unit output) = GA
     for (int ui = u_hi; ui >= u_lo; --ui) {
         const UnitInfo& u = net->units[ui];
         const long Mo = (long)u.out.N * u.out.H * u.out.W;
+        const size_t so = u.out.size, sr2 = u.r2.size, sr1 = u.r1.size, sx = u.x.size;
         auto X = [&](long off) { return [&, off](int t) -> const float* { return tw[t].ws + off; }; };
         // conv3 (1x1, bias) : input relu(bn2(r2))
-        if ((rc = bias_grad(cGA, Mo, u.depth, u.b3)) != 0) return rc;
-        if ((rc = wgrad(X(u.r2.off), cGA, u.w3, u.bn2, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0)) != 0) return rc;
-        if ((rc = dgrad(cGA, net->pack_w3[ui], T1, none, false, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0)) != 0) return rc;
-        if ((rc = bn_bwd(u.bn2, u.r2, cT1, none, false, 1, T1)) != 0) return rc;                       // T1 = d r2
+        if ((rc = bias_grad(CV(bGA, so), Mo, u.depth, u.b3)) != 0) return rc;
+        if ((rc = wgrad(X(u.r2.off), CV(bGA, so), u.w3, u.bn2, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0)) != 0) return rc;
+        if ((rc = dgrad(bGA, net->pack_w3[ui], bT1, nullptr, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0)) != 0) return rc;
+        if ((rc = bn_bwd(u.bn2, u.r2, CV(bT1, sr2), none, false, 1, V(bT1, sr2))) != 0) return rc;             // T1 = d r2
         // conv2 (3x3, stride) : input relu(bn1(r1))
-        if ((rc = wgrad(X(u.r1.off), cT1, u.w2, u.bn1, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, u.stride, 1)) != 0) return rc;
-        if ((rc = dgrad(cT1, net->pack_w2[ui], T2, none, false, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, u.stride, 1)) != 0) return rc;
-        if ((rc = bn_bwd(u.bn1, u.r1, cT2, none, false, 1, T2)) != 0) return rc;                       // T2 = d r1
+        if ((rc = wgrad(X(u.r1.off), CV(bT1, sr2), u.w2, u.bn1, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, u.stride, 1)) != 0) return rc;
+        if ((rc = dgrad(bT1, net->pack_w2[ui], bT2, nullptr, u.r1.H, u.r1.W, u.dbn, u.dbn, 3, u.stride, 1)) != 0) return rc;
+        if ((rc = bn_bwd(u.bn1, u.r1, CV(bT2, sr1), none, false, 1, V(bT2, sr1))) != 0) return rc;             // T2 = d r1
         // conv1 (1x1) : input relu(bn_pre(x))
-        if ((rc = wgrad(X(u.x.off), cT2, u.w1, u.bn_pre, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 0)) != 0) return rc;
-        if ((rc = dgrad(cT2, net->pack_w1[ui], T3, none, false, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 0)) != 0) return rc;
+        if ((rc = wgrad(X(u.x.off), CV(bT2, sr1), u.w1, u.bn_pre, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 0)) != 0) return rc;
+        if ((rc = dgrad(bT2, net->pack_w1[ui], bT3, nullptr, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 0)) != 0) return rc;
         if (u.proj) {   // projection shortcut conv1x1(preact) + bias: d preact += dgrad(G)
-            if ((rc = bias_grad(cGA, Mo, u.depth, u.b_sc)) != 0) return rc;
-            if ((rc = wgrad(X(u.x.off), cGA, u.w_sc, u.bn_pre, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 0)) != 0) return rc;
-            if ((rc = dgrad(cGA, net->pack_sc[ui], T3, cT3, true, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 0)) != 0) return rc;
-            if ((rc = bn_bwd(u.bn_pre, u.x, cT3, none, false, 1, GB)) != 0) return rc;
+            if ((rc = bias_grad(CV(bGA, so), Mo, u.depth, u.b_sc)) != 0) return rc;
+            if ((rc = wgrad(X(u.x.off), CV(bGA, so), u.w_sc, u.bn_pre, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 0)) != 0) return rc;
+            if ((rc = dgrad(bGA, net->pack_sc[ui], bT3, bT3, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 0)) != 0) return rc;
+            if ((rc = bn_bwd(u.bn_pre, u.x, CV(bT3, sx), none, false, 1, V(bGB, sx))) != 0) return rc;
         } else {        // identity shortcut (subsample by the unit's stride): d x += upsample(G)
-            if ((rc = bn_bwd(u.bn_pre, u.x, cT3, cGA, true, u.stride, GB)) != 0) return rc;
+            if ((rc = bn_bwd(u.bn_pre, u.x, CV(bT3, sx), CV(bGA, so), true, u.stride, V(bGB, sx))) != 0) return rc;
         }
-        for (int t = 0; t < T; ++t) std::swap(tw[t].GA, tw[t].GB);
+        std::swap(bGA, bGB);
     }
     if (stage == kNumStages - 1) {
         // ---- stem: max-pool backward, conv1 weight/bias gradient (the input needs no gradient)
         const TensorRef& c1 = net->t_c1;
         const TensorRef& pl = net->t_pool;
         for (int t = 0; t < T; ++t)
-            if ((rc = launch_max_pool_bwd(reinterpret_cast<const unsigned char*>(tw[t].ws + L.argmax), tw[t].GA, tw[t].GB, N, c1.H, c1.W,
-                                          c1.C, pl.H, pl.W, 3, 2, net->pool_pt, net->pool_pl, st)) != 0) return rc;
-        auto cGB = [&](int t) -> const float* { return tw[t].GB; };
+            if ((rc = launch_max_pool_bwd(reinterpret_cast<const unsigned char*>(tw[t].ws + L.argmax), bGA + (size_t)t * pl.size,
+                                          bGB + (size_t)t * c1.size, N, c1.H, c1.W, c1.C, pl.H, pl.W, 3, 2, net->pool_pt, net->pool_pl,
+                                          st)) != 0) return rc;
         auto Xin = [&](int t) -> const float* { return tw[t].ws + net->t_xin.off; };
-        if ((rc = bias_grad(cGB, (long)N * c1.H * c1.W, 64, net->b_stem)) != 0) return rc;
-        if ((rc = wgrad(Xin, cGB, net->w_stem, -1, net->H, net->W, net->in_ch_pad, 64, 7, 2, 3)) != 0) return rc;
+        if ((rc = bias_grad(CV(bGB, c1.size), (long)N * c1.H * c1.W, 64, net->b_stem)) != 0) return rc;
+        if ((rc = wgrad(Xin, CV(bGB, c1.size), net->w_stem, -1, net->H, net->W, net->in_ch_pad, 64, 7, 2, 3)) != 0) return rc;
     }
     return wgrad_reduce_flush(grads, table, st);
 }
