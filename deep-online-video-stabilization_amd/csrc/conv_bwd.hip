@@ -306,8 +306,49 @@ __global__ __launch_bounds__(256) void pack_dgrad_weights_all_kernel(const float
     wt[q] = params[d.w_off + (((size_t)co * d.K + (d.K - 1 - kh)) * d.K + (d.K - 1 - kw)) * d.Cin + ci];
 }
 
+// The same re-pack as 32 x 32 (Cout x Cin) tiles of one filter tap through LDS: 128-B runs on both sides (the element-wise
+// form above reads with a stride of K*K*Cin floats).  Needs Cout % 32 == 0 and Cin % 32 == 0 for every layer, so that a
+// layer's element prefix / 1024 is its tile prefix.
+__global__ __launch_bounds__(256) void pack_dgrad_weights_tiled_kernel(const float* __restrict__ params, float* __restrict__ wt,
+                                                                       const PackTable t) {
+    __shared__ float tile[32][33];
+    const long q = (long)blockIdx.x * 1024;
+    int lo = 0, hi = t.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.prefix[mid] <= q) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc d = t.d[lo];
+    long r = (q - t.prefix[lo]) >> 10;                    // tile index inside the layer: co tile fastest, then tap, then ci tile
+    const int cot = (int)(r % (d.Cout >> 5)); r /= (d.Cout >> 5);
+    const int kw = (int)(r % d.K); r /= d.K;
+    const int kh = (int)(r % d.K);
+    const int cit = (int)(r / d.K);
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const float* src = params + d.w_off + ((size_t)(d.K - 1 - kh) * d.K + (d.K - 1 - kw)) * d.Cin + cit * 32 + lx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = cot * 32 + ly + 8 * i;
+        tile[ly + 8 * i][lx] = src[(size_t)co * d.K * d.K * d.Cin];
+    }
+    __syncthreads();
+    float* dst = wt + t.prefix[lo] + cot * 32 + lx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ci = cit * 32 + ly + 8 * i;
+        dst[(((size_t)ci * d.K + kh) * d.K + kw) * d.Cout] = tile[lx][ly + 8 * i];
+    }
+}
+
 int pack_dgrad_weights_all(const float* params, float* wt, const PackTable& t, hipStream_t st) {
     if (t.n == 0) return STABNET_OK;
+    bool tiled = true;
+    for (int i = 0; i < t.n; ++i) tiled = tiled && t.d[i].Cout % 32 == 0 && t.d[i].Cin % 32 == 0;
+    if (tiled) {
+        pack_dgrad_weights_tiled_kernel<<<(unsigned)(t.prefix[t.n] >> 10), 256, 0, st>>>(params, wt, t);
+        SN_LAUNCH_CHECK("pack_dgrad_weights_tiled_kernel");
+        return STABNET_OK;
+    }
     pack_dgrad_weights_all_kernel<<<cdiv(t.prefix[t.n], 256), 256, 0, st>>>(params, wt, t);
     SN_LAUNCH_CHECK("pack_dgrad_weights_all_kernel");
     return STABNET_OK;

@@ -227,7 +227,12 @@ int launch_gap_bn_relu(const float* x, const float* scale, const float* shift, i
 int launch_fc(const float* x, const float* w, const float* b, float* y, int M, int K, int Nout, int relu,
               hipStream_t st) {
     SN_REQUIRE(K % 4 == 0, "fc: K %% 4 != 0");
-    for (int m0 = 0; m0 < M; m0 += 8) {
+    int m0 = 0;
+    for (; M - m0 > 8; m0 += 16) {          // 9..16 rows left: one pass (the siamese pair at 8 samples per tower)
+        fc_kernel<16><<<cdiv(Nout, 4), 256, 0, st>>>(x, w, b, y, M, K, Nout, relu, m0);
+        SN_LAUNCH_CHECK("fc_kernel");
+    }
+    if (m0 < M) {
         fc_kernel<8><<<cdiv(Nout, 4), 256, 0, st>>>(x, w, b, y, M, K, Nout, relu, m0);
         SN_LAUNCH_CHECK("fc_kernel");
     }

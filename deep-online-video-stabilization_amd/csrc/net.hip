@@ -25,6 +25,7 @@ extern "C" int stabnet_black_accumulate(const float* black, int* all_black, long
 
 enum { PK_CONV_W = 0, PK_BIAS = 1, PK_GAMMA = 2, PK_BETA = 3, PK_MEAN = 4, PK_VAR = 5, PK_FC_W = 6, PK_FC_B = 7 };
 enum { S_PAD = 0, S_CONV = 1, S_POOL = 2, S_GAP = 3, S_FC = 4 };
+static int fc_launches(int M) { int n = 0, m0 = 0; for (; M - m0 > 8; m0 += 16) ++n; return n + (m0 < M ? 1 : 0); }   // launch_fc's passes
 static const long EXT_IN = -2, EXT_OUT = -3, NONE = -1;
 
 struct ParamEntry {
@@ -641,7 +642,7 @@ int stabnet_net_num_launches(const void* netp) {
     const Net* net = static_cast<const Net*>(netp);
     if (!net) return -1;
     int n = 0;
-    for (const Step& s : net->steps) n += (s.kind == S_CONV && s.conv.splitk > 1) ? 2 : (s.kind == S_FC ? (s.M + 7) / 8 : 1);
+    for (const Step& s : net->steps) n += (s.kind == S_CONV && s.conv.splitk > 1) ? 2 : (s.kind == S_FC ? fc_launches(s.M) : 1);
     return n;
 }
 
@@ -800,6 +801,7 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
 // =========================================================================================================
 struct TrainLayout {
     size_t bn_scale, bn_shift, bn_mean, bn_invstd, GA, GB, T1, T2, T3, fcg0, fcg1, partial, fcpart, coef, wt, argmax, splitk, slabs, total;
+    size_t fcx[4];                  // FC head inputs of the PAIR ([2N, dims[k]], tower 1's rows behind tower 0's), in tower 0's workspace
     size_t fcpart_floats;
     size_t splitk_bytes, slab_floats;
 };
@@ -842,14 +844,15 @@ static TrainLayout train_layout(const Net* net) {
     // sits right behind tower 0's (buf + sz), so the pair is one [2N,...] tensor and every dgrad is ONE launch over 2N samples
     L.GA = take(2 * net->max_net); L.GB = take(2 * net->max_net); L.T1 = take(2 * net->max_r); L.T2 = take(2 * net->max_r);
     L.T3 = take(2 * net->max_net);
-    L.fcg0 = take((size_t)net->N * 2048); L.fcg1 = take((size_t)net->N * 2048);
+    L.fcg0 = take((size_t)2 * net->N * 2048); L.fcg1 = take((size_t)2 * net->N * 2048);
+    for (int k = 0; k < 4; ++k) L.fcx[k] = take((size_t)2 * net->N * net->fc_dims[k]);
     size_t red = 0;
     for (const BnInfo& b : net->bns) red = std::max(red, col_reduce_workspace_floats(b.M, b.C, 2));       // (both towers' partials)
     for (const UnitInfo& u : net->units)
         red = std::max(red, col_reduce_workspace_floats((long)u.out.N * u.out.H * u.out.W, u.depth, 2));
     red = std::max(red, col_reduce_workspace_floats((long)net->t_c1.N * net->t_c1.H * net->t_c1.W, 64, 2));
     L.partial = take(red);
-    L.fcpart_floats = (size_t)64 * net->N * 2048;            // fc_bwd_x partials: (Nout/32 <= 64 splits) x N x K
+    L.fcpart_floats = (size_t)64 * 2 * net->N * 2048;        // fc_bwd_x partials: (Nout/32 <= 64 splits) x 2N x K
     L.fcpart = take(L.fcpart_floats);
     L.coef = take(3 * std::max<size_t>(net->max_c, 2048));
     L.wt = take((size_t)net->packs.prefix[net->packs.n]);
@@ -934,13 +937,21 @@ static int run_forward_train(const Net* net, float* params, int T, const float* 
                     rc = launch_max_pool_argmax(w + s.in_off, w + s.out_off, reinterpret_cast<unsigned char*>(w + L.argmax), s.N,
                                                 s.H, s.W, s.C, s.Ho, s.Wo, s.k, s.stride, s.pt, s.pl, st);
                     break;
-                case S_GAP:
-                    rc = launch_gap_bn_relu(w + s.in_off, scale + s.bn_off, shift + s.bn_off, s.N, s.H * s.W, s.C, w + s.out_off, splitk, st);
+                case S_GAP:         // the FC head works on the pair: tower t's pooled rows go behind tower 0's
+                    rc = launch_gap_bn_relu(w + s.in_off, scale + s.bn_off, shift + s.bn_off, s.N, s.H * s.W, s.C,
+                                            ws[0] + L.fcx[0] + (size_t)t * s.N * s.C, splitk, st);
                     break;
-                case S_FC:
-                    rc = launch_fc(w + s.in_off, params + s.w_off, params + s.b_off,
-                                   s.out_off == EXT_OUT ? theta[t] : w + s.out_off, s.M, s.K, s.Nout, s.relu, st);
+                case S_FC: {
+                    int k = 0;
+                    while (k < 3 && net->fc_w[k] != s.w_off) ++k;
+                    if (s.out_off == EXT_OUT)       // output layer: theta of each tower is the caller's own buffer
+                        rc = launch_fc(ws[0] + L.fcx[3] + (size_t)t * s.M * s.K, params + s.w_off, params + s.b_off, theta[t], s.M, s.K,
+                                       s.Nout, s.relu, st);
+                    else if (t == 0)                // fc_1..3: ONE launch over the [T*N, K] pair (the weights are streamed once)
+                        rc = launch_fc(ws[0] + L.fcx[k], params + s.w_off, params + s.b_off, ws[0] + L.fcx[k + 1], T * s.M, s.K,
+                                       s.Nout, s.relu, st);
                     break;
+                }
             }
         }
         if (rc) return rc;
@@ -1022,24 +1033,27 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
 
     if (stage == 0) {
         if ((rc = pack_dgrad_weights_all(params, wt, net->packs, st)) != 0) return rc;
-        // ---- FC head (resnet.py:44-56, s_net_bundle_nobm.py:256-259), tower after tower (dW += in stream order)
-        const TensorRef* fin[4] = {&net->t_gap, &net->t_fc[0], &net->t_fc[1], &net->t_fc[2]};
+        // ---- FC head (resnet.py:44-56, s_net_bundle_nobm.py:256-259) on the pair: the output layer per tower (d_theta are the
+        // caller's buffers; dW += in tower order), fc_3..1 and the reduce_mean backward as ONE launch over [T*N, ...]
         const TensorRef& last = net->t_last;
+        float* w0 = tw[0].ws;
+        float* fg[2] = {w0 + L.fcg0, w0 + L.fcg1};
         for (int t = 0; t < T; ++t) {
-            float* w = tw[t].ws;
-            float* fg[2] = {w + L.fcg0, w + L.fcg1};
-            const float* dy = d_theta[t];
-            for (int k = 3; k >= 0; --k) {
-                const float* yk = (k < 3) ? w + net->t_fc[k].off : nullptr;         // output of layer k (ReLU mask), k < 3
-                float* dx = fg[k & 1];
-                rc = launch_fc_bwd(w + fin[k]->off, params + net->fc_w[k], yk, dy, N, net->fc_dims[k], net->fc_dims[k + 1], k < 3,
-                                   grads + net->fc_w[k], grads + net->fc_b[k], dx, w + L.fcpart, L.fcpart_floats, st);
-                if (rc) return rc;
-                dy = dx;
-            }
-            // ---- reduce_mean backward
-            if ((rc = launch_gap_bwd(dy, N, last.H * last.W, last.C, bT3 + (size_t)t * last.size, st)) != 0) return rc;
+            rc = launch_fc_bwd(w0 + L.fcx[3] + (size_t)t * N * net->fc_dims[3], params + net->fc_w[3], nullptr, d_theta[t], N,
+                               net->fc_dims[3], net->fc_dims[4], 0, grads + net->fc_w[3], grads + net->fc_b[3],
+                               fg[1] + (size_t)t * N * net->fc_dims[3], w0 + L.fcpart, L.fcpart_floats, st);
+            if (rc) return rc;
         }
+        const float* dy = fg[1];
+        for (int k = 2; k >= 0; --k) {
+            float* dx = fg[k & 1];
+            rc = launch_fc_bwd(w0 + L.fcx[k], params + net->fc_w[k], w0 + L.fcx[k + 1], dy, T * N, net->fc_dims[k], net->fc_dims[k + 1], 1,
+                               grads + net->fc_w[k], grads + net->fc_b[k], dx, w0 + L.fcpart, L.fcpart_floats, st);
+            if (rc) return rc;
+            dy = dx;
+        }
+        // ---- reduce_mean backward
+        if ((rc = launch_gap_bwd(dy, T * N, last.H * last.W, last.C, bT3, st)) != 0) return rc;
         // ---- postnorm BN + ReLU
         if ((rc = bn_bwd(net->bn_post, last, CV(bT3, last.size), none, false, 1, V(bGA, last.size))) != 0) return rc;
     }

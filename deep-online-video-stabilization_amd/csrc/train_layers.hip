@@ -345,10 +345,27 @@ __global__ __launch_bounds__(256) void weight_decay_kernel(const float* __restri
     const long off = seg_off[sgi], len = seg_len[sgi];
     const float coef = seg_coef[sgi];
     float s = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < len; i += (long)gridDim.x * 256) {
+    // scalar head up to the first 16-B boundary, float4 body, scalar tail (the fixed thread <-> element map keeps the sum reproducible)
+    const long head = min(len, (long)((4 - ((off) & 3)) & 3));
+    const long body = (len - head) >> 2;
+    const float gc = gscale * coef;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t < head + ((len - head) & 3)) {
+        const long i = t < head ? t : head + 4 * body + (t - head);
         const float w = params[off + i];
         s += w * w;
-        if (grads != nullptr) grads[off + i] += gscale * coef * w;
+        if (grads != nullptr) grads[off + i] += gc * w;
+    }
+    const float4* p4 = reinterpret_cast<const float4*>(params + off + head);
+    float4* g4 = reinterpret_cast<float4*>(grads != nullptr ? grads + off + head : nullptr);
+    for (long i = t; i < body; i += (long)gridDim.x * 256) {
+        const float4 w = p4[i];
+        s += (w.x * w.x + w.y * w.y) + (w.z * w.z + w.w * w.w);
+        if (grads != nullptr) {
+            float4 g = g4[i];
+            g.x += gc * w.x; g.y += gc * w.y; g.z += gc * w.z; g.w += gc * w.w;
+            g4[i] = g;
+        }
     }
     if (partial != nullptr) {
         for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
