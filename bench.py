@@ -167,22 +167,25 @@ def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
         if rank == 0:
             roof["whole_step_tflops"] = out["step_gflop_algorithmic"] / out["ms_per_step"]
             roof["whole_step_frac"] = roof["whole_step_tflops"] / PEAK_F32_MFMA_TFLOPS
+            roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], (N, H, W) == (8, 288, 512), PMC_FILE_TRAIN)
             out["roofline"] = roof
             out["kernels"] = table[:6]
     return out
 
 
 PMC_FILE = os.path.join("profiles", "r02_pmc_hbm_traffic_bench720p.json")
+PMC_FILE_TRAIN = os.path.join("profiles", "r02_pmc_hbm_traffic_train_b8.json")
 
 
-def pmc_traffic(kernel, workload_is_default):
+def pmc_traffic(kernel, workload_is_default, pmc_file=None):
     """(HBM bytes per launch of `kernel`, note) from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected
     in separate runs of this same command, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  Only valid for the
     default 720p workload AND for the kernel sources the passes were taken on (the file carries their hash): otherwise
     (None, why)."""
+    PMC_FILE = pmc_file or globals()["PMC_FILE"]
     path = os.path.join(ROOT, PMC_FILE)
     if not workload_is_default:
-        return None, "PMC passes exist for the default 720p workload only"
+        return None, "PMC passes exist for the default workloads only (720p batch 1; training 8 pairs at 288x512)"
     if not os.path.exists(path):
         return None, "no %s (run tools/refresh_profiles.sh on the GPU box)" % PMC_FILE
     try:

@@ -2,7 +2,7 @@
 """Aggregate two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same bench command) into HBM bytes
 per launch per kernel.  FETCH_SIZE is doubled (gfx950 counts 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM /
 rocprofv3 section); WRITE_SIZE is taken as is.  Both counters are in KB.
-  python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
+  python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [command text for the file's header]"""
 import csv, glob, json, os, sys
 
 
@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import csrc_sha16  # noqa: E402  (the stamp bench.py checks before it reports `traffic`)
 
 fetch, write = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE")
-out = {"__meta__": {"csrc_sha16": csrc_sha16(), "command": "bench.py --steps 20 --warmup 5 (720p, batch 1)",
+out = {"__meta__": {"csrc_sha16": csrc_sha16(), "command": sys.argv[4] if len(sys.argv) > 4 else "bench.py --steps 20 --warmup 5 (720p, batch 1)",
                     "correction": "FETCH_SIZE x2 (gfx950 counts 128-B reads at 64 B), WRITE_SIZE as is; both in KB"}}
 for k, (n, fkb) in sorted(fetch.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
     wkb = write.get(k, (0, 0.0))[1]
