@@ -884,7 +884,7 @@ static const BnInfo* find_bn(const Net* net, long chan_off) {
 }
 
 // T = 1: one tower.  T = 2: the two siamese towers (train_bundle_nobm.py:107-108, same weights) layer by layer in LOCKSTEP:
-// every convolution / pool / FC is launched for tower 0 and then for tower 1 (the weights are L2 / Infinity-Cache hot for the
+// every convolution / pool is launched for tower 0 and then for tower 1 (the weights are L2 / Infinity-Cache hot for the
 // second launch), and every batch-statistics reduction covers both towers in ONE launch (launch_*_g: these kernels are
 // launch-latency sized).  Scratch that lives for one launch only (reduction partials, split-K slabs, the re-packed dgrad
 // weights) is taken from tower 0's workspace; everything a tower keeps for its backward is in its own.
@@ -1171,7 +1171,7 @@ int stabnet_tower_bwd_stage(const void* netp, const float* params, const float* 
     float* ws[1] = {static_cast<float*>(workspace)};
     return run_backward_stage(net, params, 1, &d_theta, grads, ws, stage, (hipStream_t)stream, static_cast<Prof*>(prof));
 }
-/* One backward stage of BOTH towers in lockstep (see stabnet_towers_fwd_train): per layer one wgrad / dgrad launch per tower,
+/* One backward stage of BOTH towers in lockstep (see stabnet_towers_fwd_train): per layer ONE wgrad and ONE dgrad launch for the pair,
  * one BN-backward reduction / finalize / apply and one bias-gradient reduction for both, the dgrad weights re-packed once,
  * one slab reduction per stage.  After stage k the bucket stabnet_net_grad_bucket(k) holds the sum of both towers. */
 int stabnet_towers_bwd_stage(const void* netp, const float* params, const float* d_theta1, const float* d_theta2, float* grads,
