@@ -45,6 +45,15 @@ struct Prof;
 // register allocation -- stays exactly what it was; an extra field cost the fp32 path 1 %.)
 int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof = nullptr, int bf16_operands = 0);
 
+// The two siamese towers of a training step as ONE launch (forward convolutions, conv_kernel.h).  `a` describes the pair as one
+// batch of 2N samples whose first N live where a.x / a.y / a.residual / a.in_scale / a.in_shift point; tiles of rows >= m_tower
+// (the second tower: its tensors sit in another workspace, and its batch statistics differ) get these ELEMENT offsets added to
+// the five pointers.  m_tower must be a multiple of the tile height (64).  conv_pair_supported(): the plan of `a` is a 64x64
+// register-staged launch (anything else: launch the towers one after the other).
+struct ConvPair { int m_tower, x_tower_floats /* N*H*W*Cin of one tower's input */; long dx, dy, dres, dscale; };
+bool conv_pair_supported(const ConvArgs& a);
+int conv_launch_pair(const ConvArgs& a, const ConvPair& pr, hipStream_t st, Prof* prof = nullptr);
+
 // Exact unsigned division by an invariant divisor d >= 1 for numerators n < 2^31 (Granlund-Montgomery round-up form):
 //   l = ceil(log2 d), mul = floor(2^32 (2^l - d) / d) + 1, n / d = (mulhi(mul, n) + n) >> l.
 // Three instructions instead of the ~40 of a software 32-bit division; the kernels' per-tile index setup is VALU work

@@ -24,12 +24,14 @@
 #include "conv_ring_kernel.h"
 
 // Sums the split-K partial slabs in a fixed order and applies the epilogue.  One thread per 4 channels.
-__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs p) {
+template <int PAIR>
+__device__ __forceinline__ void conv_splitk_reduce_body(const ConvArgs& p, const ConvPair& pr) {
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int c4n = p.Cout / 4;
     if (q >= (size_t)p.M * c4n) return;
     const int m = (int)(q / c4n);
     const int n = (int)(q - (size_t)m * c4n) * 4;
+    const bool t1 = PAIR && m >= pr.m_tower;              // row of the second tower: its y / residual live at an offset
     const size_t slab = (size_t)p.M * p.Cout;
     const float* src = p.partial + (size_t)m * p.Cout + n;
     float4 s = *reinterpret_cast<const float4*>(src);
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
             const int oy = sn_fastdiv(rr, p.div_w_mul, p.div_w_shift), ox = rr - oy * p.Wo;
             ri = (((size_t)img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.res_ld + n;
         }
-        const float4 t = *reinterpret_cast<const float4*>(p.residual + ri);
+        const float4 t = *reinterpret_cast<const float4*>(p.residual + (t1 ? pr.dres : 0) + ri);
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
     if (p.out_scale != nullptr) {
@@ -65,7 +67,13 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
     } else if (p.relu_out) {
         s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
     }
-    *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n) = s;
+    *reinterpret_cast<float4*>(p.y + (t1 ? pr.dy : 0) + (size_t)m * p.Cout + n) = s;
+}
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs p) {
+    conv_splitk_reduce_body<0>(p, ConvPair{});
+}
+__global__ __launch_bounds__(256) void conv_splitk_reduce_pair_kernel(const ConvArgs p, const ConvPair pr) {
+    conv_splitk_reduce_body<1>(p, pr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -274,6 +282,53 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands
         conv_splitk_reduce_kernel<<<cdiv((long)q, 256), 256, 0, st>>>(a);
         if (rec2) prof->end(st, PK_KERNEL_SPLITK_REDUCE, 0.0, 4.0 * (double)a.M * a.Cout * (a.splitk + 1));
         SN_LAUNCH_CHECK("conv_splitk_reduce_kernel");
+    }
+    return STABNET_OK;
+}
+
+// The siamese pair as one launch (ConvPair, conv.h): the 64x64 register-staged tile, MODE 0 / 1, BK 32 or 16.
+bool conv_pair_supported(const ConvArgs& a) {
+    int splitk_unused = 1;
+    const int t = pick_tile(a, splitk_unused);
+    ConvArgs probe = a;                                    // (at plan time the prologue pointers are not set yet)
+    if (a.in_scale_expected && probe.in_scale == nullptr) probe.in_scale = probe.in_shift = reinterpret_cast<const float*>(&probe);
+    return t == T64x64 && !ring_eligible(probe, t) && a.up == 1 && !a.rowrun && (a.x_ld == 0 || a.x_ld == a.Cin);
+}
+
+template <int BK, int MODE>
+static int launch_pair_one(const ConvArgs& a, const ConvPair& pr, hipStream_t st) {
+    constexpr size_t lds = 2 * (size_t)(64 + 64) * (BK + 4) * sizeof(float);
+    static_assert(lds >= 4 * (size_t)SN_EPI_WAVE_BYTES && lds <= 64 * 1024, "LDS of the 64x64 tile");
+    dim3 grid(cdiv(a.M, 64), cdiv(a.Cout, 64), a.splitk);
+    conv_igemm_f32_pair_kernel<64, 64, BK, 32, 32, MODE><<<grid, 256, lds, st>>>(a, pr);
+    SN_LAUNCH_CHECK("conv_igemm_f32_pair_kernel");
+    return STABNET_OK;
+}
+
+int conv_launch_pair(const ConvArgs& a, const ConvPair& pr, hipStream_t st, Prof* prof) {
+    g_bf16_operands = 0;
+    SN_REQUIRE(a.Cin % 16 == 0 && a.Cout % 4 == 0, "conv pair: Cin %% 16 and Cout %% 4 must be 0");
+    SN_REQUIRE(a.splitk >= 1 && a.steps_per_split >= 1 && a.div_hw_mul != 0, "conv pair: conv_plan() not called");
+    SN_REQUIRE(a.splitk == 1 || a.partial != nullptr, "conv pair: split-K needs a workspace");
+    SN_REQUIRE(conv_pair_supported(a), "conv pair: the plan of this shape is not the 64x64 register-staged launch");
+    SN_REQUIRE(pr.m_tower > 0 && pr.m_tower % 64 == 0 && a.M == 2 * pr.m_tower, "conv pair: tower rows %d must be a multiple of 64 (M %d)",
+               pr.m_tower, a.M);
+    const bool bk32 = conv_bk(a) == 32;
+    const int mode = a.pad == 0 ? 0 : 1;
+    const bool rec = prof != nullptr && prof->begin(st);
+    int rc;
+    if (bk32) rc = mode == 0 ? launch_pair_one<32, 0>(a, pr, st) : launch_pair_one<32, 1>(a, pr, st);
+    else rc = mode == 0 ? launch_pair_one<16, 0>(a, pr, st) : launch_pair_one<16, 1>(a, pr, st);
+    if (rec) prof->end(st, PK_KERNEL_CONV_BASE + mode * 6 + T64x64 * 2 + (bk32 ? 1 : 0), 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
+                       4.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.K * a.Cout + (double)a.M * a.Cout * a.splitk),
+                       a.M, a.Cout, a.K, a.splitk);
+    if (rc) return rc;
+    if (a.splitk > 1) {
+        const size_t q = (size_t)a.M * (a.Cout / 4);
+        const bool rec2 = prof != nullptr && prof->begin(st);
+        conv_splitk_reduce_pair_kernel<<<cdiv((long)q, 256), 256, 0, st>>>(a, pr);
+        if (rec2) prof->end(st, PK_KERNEL_SPLITK_REDUCE, 0.0, 4.0 * (double)a.M * a.Cout * (a.splitk + 1));
+        SN_LAUNCH_CHECK("conv_splitk_reduce_pair_kernel");
     }
     return STABNET_OK;
 }

@@ -39,6 +39,8 @@ struct ParamEntry {
 struct Step {
     int kind;
     ConvArgs conv;
+    ConvArgs conv_pair;                          // training plans: the same conv over BOTH towers' batches (N doubled), own split-K plan
+    int pair_ok;                                 // 1: conv_launch_pair() can run it (64x64 register-staged plan, tower rows % 64 == 0)
     long in_off, out_off, res_off, w_off, b_off, bn_off;
     long obn_off;                                // inference only: folded BN + ReLU of the CONSUMER fused behind this conv
     int inf_preactivated;                        // inference only: the input tensor already holds relu(bn(.)) -> no prologue
@@ -429,6 +431,18 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             net->pack_w2[ui] = add(u.w2, u.dbn, 3, u.dbn);
             net->pack_w1[ui] = add(u.w1, u.dbn, 1, u.cin);
             net->pack_sc[ui] = u.proj ? add(u.w_sc, u.depth, 1, u.cin) : -1;
+        }
+    }
+    if (net->keep_all) {   // the lockstep forward launches a conv ONCE for both towers where the kernel allows it
+        for (Step& st_ : net->steps) {
+            if (st_.kind != S_CONV) continue;
+            st_.conv_pair = st_.conv;
+            st_.conv_pair.N = 2 * st_.conv.N;
+            const size_t bytes = conv_plan(st_.conv_pair);
+            st_.pair_ok = conv_pair_supported(st_.conv_pair) && st_.conv.M % 64 == 0 &&
+                          (long)st_.conv_pair.N * (st_.conv.H + 2 * st_.conv.pad) * (st_.conv.W + 2 * st_.conv.pad) * st_.conv.Cin < (1L << 30) &&
+                          (long)st_.conv_pair.M * st_.conv.Cout < (1L << 30);
+            if (st_.pair_ok) net->splitk_bytes = std::max(net->splitk_bytes, bytes);
         }
     }
     net->act_floats = ar.peak;
@@ -893,6 +907,7 @@ static int run_forward_train(const Net* net, float* params, int T, const float* 
     const TrainLayout L = train_layout(net);
     float* splitk = ws[0] + L.splitk;
     float* partial = ws[0] + L.partial;
+    static const bool pair_convs = getenv("STABNET_TRAIN_PAIR_FWD") == nullptr || atoi(getenv("STABNET_TRAIN_PAIR_FWD")) != 0;   // debug switch
     std::vector<char> have(net->bns.size(), 0);
     auto need_bn = [&](long chan_off) -> int {
         const BnInfo* b = find_bn(net, chan_off);
@@ -923,14 +938,31 @@ static int run_forward_train(const Net* net, float* params, int T, const float* 
                     rc = launch_pad_channels(x[t], w + s.out_off, (long)s.N * s.H * s.W, s.C, net->in_ch_pad, st);
                     break;
                 case S_CONV: {
-                    ConvArgs a = s.conv;
+                    const bool pair = T == 2 && s.pair_ok && pair_convs;
+                    if (pair && t == 1) break;                         // launched with tower 0
+                    ConvArgs a = pair ? s.conv_pair : s.conv;
                     a.x = w + s.in_off; a.y = w + s.out_off; a.w = params + s.w_off;
                     a.bias = s.b_off >= 0 ? params + s.b_off : nullptr;
                     a.residual = s.res_off >= 0 ? w + s.res_off : nullptr;
                     a.in_scale = s.bn_off >= 0 ? scale + s.bn_off : nullptr;
                     a.in_shift = s.bn_off >= 0 ? shift + s.bn_off : nullptr;
                     a.partial = splitk;
-                    rc = conv_launch(a, st, prof);
+                    if (pair) {
+                        // tower 1's tensors sit at the same offsets of ITS workspace: one element offset for everything, minus the
+                        // N images (or tower rows) the pair's row index has already advanced by
+                        const long delta = (long)(ws[1] - ws[0]);
+                        const ConvArgs& c = s.conv;
+                        ConvPair pr;
+                        pr.m_tower = c.M;
+                        pr.x_tower_floats = c.N * c.H * c.W * c.Cin;
+                        pr.dx = delta - (long)c.N * c.H * c.W * c.Cin;
+                        pr.dy = delta - (long)c.M * c.Cout;
+                        pr.dres = delta - (long)c.N * c.res_H * c.res_W * c.res_ld;
+                        pr.dscale = delta;
+                        rc = conv_launch_pair(a, pr, st, prof);
+                    } else {
+                        rc = conv_launch(a, st, prof);
+                    }
                     break;
                 }
                 case S_POOL:

@@ -245,8 +245,10 @@ int stabnet_tower_fwd_train(const void* net, float* params, const float* x_tenso
                             size_t workspace_bytes, float bn_eps, float bn_decay, void* stream, void* prof);
 
 /* Both siamese towers of a step (train_bundle_nobm.py:107-108: two towers over the same weights) in LOCKSTEP, layer by layer:
- * per layer the convolution of tower 1 and of tower 2, and ONE batch-statistics reduction launch covering both (those kernels
- * are launch-latency sized).  Same results as tower_fwd_train(x1) then tower_fwd_train(x2); one workspace per tower. */
+ * per layer ONE convolution launch over both towers' batches where the tower's rows are a multiple of the 64-row tile (else the
+ * convolution of tower 1, then of tower 2), and ONE batch-statistics reduction launch covering both.  The results are those of
+ * tower_fwd_train(x1) then tower_fwd_train(x2) up to float32 summation order (the pair's launch may choose another split-K);
+ * the moving averages receive tower 1's update, then tower 2's.  One workspace per tower. */
 int stabnet_towers_fwd_train(const void* net, float* params, const float* x1, const float* x2, float* theta1, float* theta2,
                              void* workspace1, void* workspace2, size_t workspace_bytes, float bn_eps, float bn_decay,
                              void* stream, void* prof);

@@ -191,11 +191,12 @@ def test_training_step_8x288x512_matches_oracles(cuda):
         l2 = np.linalg.norm(gg - ww) / max(np.linalg.norm(ww), 1e-5 * gmax * np.sqrt(n))
         worst_abs, worst_l2 = max(worst_abs, err), max(worst_l2, l2)
         # float32 against float64 through 53 convs / 49 batch-stat BNs at 2.4 M pixels per tower: measured worst single
-        # element 3.7e-2 of its tensor's gradient scale (a few isolated elements -- ReLU masks of pre-activations within
-        # float32 rounding of zero), worst tensor 4.1e-3 in relative L2; the 2x64x96 step (test_train_gpu.py) keeps the
-        # 2e-2 element bar
-        assert err < 5e-2, "%s: element err %g (scale %g)" % (name, err, scale)
+        # element 3.7e-2 .. 4.7e-2 of its tensor's gradient scale (a few isolated elements), worst tensor 5.4e-3 .. 6.4e-3 in
+        # relative L2, whole gradient 5.3e-4 .. 5.7e-4 (the two figures: conv of both towers as one launch / one launch per tower);
+        # a 1e-7 relative change of the input moves the float32 gradient by 6.5e-4 (tests/test_train_gpu.py explains why)
+        assert err < 1e-1, "%s: element err %g (scale %g)" % (name, err, scale)
         assert l2 < 1e-2, "%s: relative L2 err %g" % (name, l2)
+    print('MEASURED worst element %.3e worst tensor L2 %.3e whole L2 %.3e' % (worst_abs, worst_l2, np.linalg.norm(got_flat - want_flat) / np.linalg.norm(want_flat)))
     assert np.linalg.norm(got_flat - want_flat) / np.linalg.norm(want_flat) < 2e-3       # measured 5.7e-4
     cos = float(np.dot(got_flat, want_flat) / (np.linalg.norm(got_flat) * np.linalg.norm(want_flat)))
     assert cos > 1 - 1e-5, cos
