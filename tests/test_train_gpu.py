@@ -51,25 +51,16 @@ def test_training_step_matches_autograd_oracle(cuda):
     # backward: every trainable tensor, error relative to that tensor's gradient scale
     got_flat = tr.grad_flat().cpu().numpy()
     want_flat = tr.plan.pack({k: want_g[k] for k in P})[:tr.nt]
-    # How well-conditioned is what is being compared?  The same step on inputs changed by a ROUNDING-sized relative amount
-    # (1e-7) moves the float32 gradient by ~2e-3 (whole vector, relative L2) at this size: batch statistics over 12..48 values per
-    # channel in block3 / block4, the BN backward right behind reduce_mean subtracts a per-channel constant from an almost
-    # constant gradient (cancellation), and the losses pick pixels discretely (round(), strict black comparisons).  So two
-    # correct float32 evaluations that differ in summation order differ by that much (measured: the lockstep forward that runs
-    # a conv of both towers as one launch vs one launch per tower: 1.9e-3; tools/scratch/pairfwd_compare.py), and the bars
-    # below are set from it: the error against float64 must stay within 3x that change (or 5e-4), plus fixed per-tensor bars.
-    # At 8 x 288 x 512 (tests/test_baseline_sizes_gpu.py) the same quantities are 5e-4 whole, 6e-3 worst tensor.
-    rng = np.random.default_rng(11)
-    b2 = dict(b)
-    for k in ("x1", "x2"):
-        b2[k] = (b[k] * (1.0 + 1e-7 * rng.standard_normal(b[k].shape))).astype(np.float32)
-    p_keep = tr.params.clone()
-    tr.forward_backward({k: torch.from_numpy(v).to(cuda) for k, v in b2.items()}, gates, apply_update=False)
-    torch.cuda.synchronize()
-    pert_flat = tr.grad_flat().cpu().numpy()
-    tr.params.copy_(p_keep)                       # (the moving averages checked below are those of the unperturbed step)
-    noise = np.linalg.norm(pert_flat.astype(np.float64) - got_flat) / np.linalg.norm(got_flat)
-
+    # What the bars below allow for.  The objective is not smooth: `black_pix` is a strict comparison of the warp map with +-1
+    # (spatial_transformer3.py:284-286), the feature loss rounds pixel coordinates (s_net_bundle_nobm.py:218-221), ReLU masks and
+    # the max-pool argmax are discrete.  A float32 evaluation whose theta differs from the float64 one in the 7th digit can take
+    # the other side of such a decision: measured here (tools/scratch/pairfwd_compare.py, this configuration), forcing another
+    # split-K on every convolution moves the whole gradient by 1.5e-4 (relative L2) -- and both a 1e-7 relative change of the input
+    # and the lockstep forward that runs a conv of both towers as ONE launch move it by the SAME 2.2e-3, i.e. the same discrete
+    # decision flips (black-pixel counts and feature loss unchanged, img_loss of tower 2 changes in its 6th digit: what is left
+    # is a sampler cell boundary -- d/d map of a bilinear sample jumps there -- or a ReLU / arg-max choice).  So the error against
+    # float64 is 1.7e-4 on one side of that decision and 2.4e-3 on the other; at 8 x 288 x 512 (tests/test_baseline_sizes_gpu.py),
+    # where one pixel weighs 24x less, both variants measure 5.3e-4 .. 5.7e-4.
     gmax = np.abs(want_flat).max()
     worst_abs = worst_l2 = 0.0
     for name, off, kind, dims, aux in tr.plan.table:
@@ -83,12 +74,11 @@ def test_training_step_matches_autograd_oracle(cuda):
         err = np.abs(gg - ww).max() / scale
         l2 = np.linalg.norm(gg - ww) / max(np.linalg.norm(ww), 1e-5 * gmax * np.sqrt(n))
         worst_abs, worst_l2 = max(worst_abs, err), max(worst_l2, l2)
-        assert err < 1.5e-1, "%s: element err %g (scale %g)" % (name, err, scale)      # measured 1.4e-2 .. 8.4e-2 (see above)
+        assert err < 1.5e-1, "%s: element err %g (scale %g)" % (name, err, scale)      # measured 1.4e-2 .. 8.4e-2 (the two sides, see above)
         assert l2 < 2e-2, "%s: relative L2 err %g" % (name, l2)                         # measured 3.6e-3 .. 8.7e-3
     whole = np.linalg.norm(got_flat - want_flat) / np.linalg.norm(want_flat)
-    print("MEASURED worst element %.3e worst tensor L2 %.3e whole L2 %.3e; a 1e-7 input change moves the gradient by %.3e"
-          % (worst_abs, worst_l2, whole, noise))
-    assert whole < max(5e-4, 3.0 * noise), (whole, noise)                                # measured 1.7e-4 .. 2.4e-3 vs noise 1.9e-3
+    print("MEASURED worst element %.3e worst tensor L2 %.3e whole L2 %.3e" % (worst_abs, worst_l2, whole))
+    assert whole < 5e-3, whole                                                          # measured 1.7e-4 .. 2.4e-3 (see above)
     cos = float(np.dot(got_flat, want_flat) / (np.linalg.norm(got_flat) * np.linalg.norm(want_flat)))
     assert cos > 1 - 1e-5, "gradient cosine %r, worst tensor element err %g" % (cos, worst_abs)
 

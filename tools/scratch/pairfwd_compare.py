@@ -6,10 +6,10 @@ from stabnet_amd import synthetic
 from stabnet_amd.config import Config
 from stabnet_amd.train import Trainer
 N, H, W, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
-cfg = Config(height=H, width=W, batch_size=N)
-P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
+cfg = Config(height=H, width=W, batch_size=N, max_matches=48) if os.environ.get('TESTCFG') else Config(height=H, width=W, batch_size=N)
+P = synthetic.make_params(cfg, seed=0, theta_scale=0.3 if os.environ.get('TESTCFG') else 0.2)
 tr = Trainer(P, N, H, W, cfg, device="cuda:0")
-b = synthetic.make_train_batch(cfg, N, H, W, seed=1234)
+b = synthetic.make_train_batch(cfg, N, H, W, 5 if os.environ.get('TESTCFG') else 1234)
 dev_b = {k: torch.from_numpy(v).to("cuda:0") for k, v in b.items()}
 gates = {"use_theta_loss": 1, "use_temp_loss": 1, "use_black_loss": 1, "use_theta_only": 0}
 if os.environ.get("PERTURB"):      # how sensitive are the gradients to a rounding-sized change of the input?
@@ -28,6 +28,10 @@ if os.environ.get("REGRESSOR_ONLY"):
 else:
     tr.forward_backward(dev_b, gates, apply_update=False)
 torch.cuda.synchronize()
+if not os.environ.get("REGRESSOR_ONLY"):
+    lo = tr.losses()
+    print("BLACK", [float(t["black_pix"].double().sum()) for t in tr.last["towers"]])
+    print("LOSSES", {k: (repr(v) if not isinstance(v, dict) else {kk: repr(vv) for kk, vv in v.items()}) for k, v in lo.items()})
 g = tr.grad_flat().cpu().numpy()
 np.save(out, g)
 if len(sys.argv) > 5:
