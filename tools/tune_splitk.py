@@ -152,7 +152,8 @@ L.stabnet_conv_tuning_table_set(-1, 0, 0, 0, 0, 0)
 with open(a.out, "w") as f:
     f.write("// Measured split-K choices {M, Cout, K, KH, ring, splitk}; GENERATED by tools/tune_splitk.py on MI355X -- do not edit.\n")
     f.write("// Workloads: deploy batch 1 at 1280x720, 1920x1080, 512x288 and 256x256 (BASELINE configs[1], [4], the reference's native\n")
-    f.write("// size, configs[0]); training 8 pairs at 288x512 (forward with BN prologue: ring 0; dgrad: ring 1).\n")
+    f.write("// size, configs[0]); training 8 pairs at 288x512 (forward with BN prologue: ring 0, both towers as one launch where the\n")
+    f.write("// tile allows it, i.e. M of 16 samples; dgrad of the pair: ring 1).\n")
     f.write("// Per shape: the smallest split within 1 % of the fastest measured one (kernel + reduce launch + launch gap, in-network).\n")
     f.write("static const TuneEntry g_tuning_builtin[] = {\n")
     for (M, N, K, kh, ring), s in sorted(table.items()):
