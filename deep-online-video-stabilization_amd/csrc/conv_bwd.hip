@@ -155,6 +155,148 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs p) 
     }
 }
 
+// The same product for "same"-geometry convolutions at stride 1 (1x1 pad 0, 3x3 pad 1: 50 of the 53 layers of the regressor),
+// with the K loop's address work moved out of the vector ALU.  There the output pixel m and its input pixel share one linear
+// index, so both operands advance by a CONSTANT per 32-pixel step: dY rows by 32*Cout floats, x rows by 32*Cin floats -- a
+// scalar running base plus a loop-invariant per-lane byte offset (the `saddr + voffset` load form).  Only the 3x3 needs per-row
+// state: the (iy, ix) of its tap, advanced by (32 / W, 32 % W) with carries, to know whether the tap is in frame (an out-of-frame
+// tap loads the row's own centre pixel instead -- always in frame -- and is zeroed).  The general kernel above recomputes pixel
+// coordinates with divisions-by-loop and 64-bit addresses every step: 103 VALU instructions per 16 MFMAs, and on gfx950 every
+// VALU instruction costs ~3 cycles of f32-MFMA issue.  Requirements (host-checked): stride 1, Ho == H,
+// Wo == W, M % 32 == 0, Cout % 64 == 0, K % 64 == 0, Cin % 4 == 0, 32 / W + 1 < H.
+template <int K3>
+__global__ __launch_bounds__(256) void conv_wgrad_same_f32_kernel(const WgradArgs p) {
+    constexpr int BR = 32, BT = 64;
+    __shared__ __attribute__((aligned(16))) float sY[2][BR][BT];
+    __shared__ __attribute__((aligned(16))) float sA[2][BR][BT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * BT, k0 = blockIdx.y * BT;
+    const int tower = (int)blockIdx.z >= p.splits_per_tower ? 1 : 0;
+    const int zsplit = (int)blockIdx.z - tower * p.splits_per_tower;
+    const float* __restrict__ px = tower ? p.x2 : p.x;
+    const float* __restrict__ pdy = tower ? p.dy2 : p.dy;
+    const float* __restrict__ pscale = tower ? p.in_scale2 : p.in_scale;
+    const float* __restrict__ pshift = tower ? p.in_shift2 : p.in_shift;
+    const int m_begin = zsplit * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    if (m_begin >= m_end) return;
+    const int steps = (m_end - m_begin) / BR;                  // exact: M and rows_per_split are multiples of 32
+
+    const int lq = tid & 15, lr = tid >> 4;                    // float4 column, pixel rows lr and lr + 16
+    const int kcol = k0 + lq * 4;
+    const int tap = K3 ? kcol / p.Cin : 0;
+    const int c_t = kcol - tap * p.Cin;
+    const int kh = K3 ? tap / 3 : 0, kw = K3 ? tap - kh * 3 : 0;
+    const int pad = K3 ? 1 : 0;
+    const bool has_pro = pscale != nullptr;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_pro) {
+        sc = *reinterpret_cast<const float4*>(pscale + c_t);
+        sh = *reinterpret_cast<const float4*>(pshift + c_t);
+    }
+    // loop-invariant per-lane byte offsets from the running (wave-uniform) bases
+    unsigned voff_y[2], voff_a[2], voff_c[2];
+    int iy[2], ix[2];                                          // K3: input coordinates of this lane's tap for its two rows
+    const int HW = p.H * p.W;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = lr + 16 * t;
+        voff_y[t] = 4u * (unsigned)(row * p.Cout + n0 + lq * 4);
+        voff_a[t] = 4u * (unsigned)((row + kh * p.W + kw) * p.Cin + c_t);
+        voff_c[t] = 4u * (unsigned)((row + pad * p.W + pad) * p.Cin + c_t);
+        const int m = m_begin + row;
+        const int r = m - (m / HW) * HW;
+        const int oy = r / p.W;
+        iy[t] = oy + kh - pad;
+        ix[t] = r - oy * p.W + kw - pad;
+    }
+    const char* sy = reinterpret_cast<const char*>(pdy + (size_t)m_begin * p.Cout);
+    const char* sa = reinterpret_cast<const char*>(px + ((long)m_begin - pad * p.W - pad) * p.Cin);   // (may point in front of x)
+    const size_t y_step = (size_t)BR * p.Cout * 4, a_step = (size_t)BR * p.Cin * 4;
+    const int dq = BR / p.W, dr = BR - dq * p.W;               // a step advances a row by dq image rows and dr columns
+    const int x_hi = p.W + kw - pad, y_hi = p.H + kh - pad;    // wrap bounds in the shifted (tap) coordinates
+
+    // (scalars and macros, not arrays captured by lambdas: with arrays the compiler parked the loaded tile in scratch memory and
+    //  waited for the loads right behind their issue)
+    float4 ry0, ry1, ra0, ra1;
+    bool ok0 = true, ok1 = true;
+    int iy0 = iy[0], iy1 = iy[1], ix0 = ix[0], ix1 = ix[1];
+    const unsigned vy0 = voff_y[0], vy1 = voff_y[1], va0 = voff_a[0], va1 = voff_a[1], vc0 = voff_c[0], vc1 = voff_c[1];
+#define SN_WG_LOAD_ROW(RY, RA, OK, IY, IX, VY, VA, VC)                                            \
+    do {                                                                                          \
+        unsigned va_ = (VA);                                                                      \
+        if (K3) {                                                                                 \
+            OK = (unsigned)(IY) < (unsigned)p.H && (unsigned)(IX) < (unsigned)p.W;                \
+            va_ = OK ? va_ : (VC);                                                                \
+            IX += dr;                                                                             \
+            const bool wrap_ = IX >= x_hi;                                                        \
+            IX -= wrap_ ? p.W : 0;                                                                \
+            IY += dq + (wrap_ ? 1 : 0);                                                           \
+            IY -= (IY >= y_hi) ? p.H : 0;                                                         \
+        }                                                                                         \
+        RY = *reinterpret_cast<const float4*>(sy + (VY));                                         \
+        RA = *reinterpret_cast<const float4*>(sa + va_);                                          \
+    } while (0)
+#define SN_WG_LOAD_TILES()                                                 \
+    do {                                                                   \
+        SN_WG_LOAD_ROW(ry0, ra0, ok0, iy0, ix0, vy0, va0, vc0);            \
+        SN_WG_LOAD_ROW(ry1, ra1, ok1, iy1, ix1, vy1, va1, vc1);            \
+        sy += y_step;                                                      \
+        sa += a_step;                                                      \
+    } while (0)
+#define SN_WG_STORE_ROW(RY, RA, OK, ROW, BUF)                                                     \
+    do {                                                                                          \
+        float4 a_ = (RA);                                                                         \
+        if (has_pro) {                                                                            \
+            a_.x = fmaxf(__builtin_fmaf(a_.x, sc.x, sh.x), 0.f);                                  \
+            a_.y = fmaxf(__builtin_fmaf(a_.y, sc.y, sh.y), 0.f);                                  \
+            a_.z = fmaxf(__builtin_fmaf(a_.z, sc.z, sh.z), 0.f);                                  \
+            a_.w = fmaxf(__builtin_fmaf(a_.w, sc.w, sh.w), 0.f);                                  \
+        }                                                                                         \
+        if (K3 && !(OK)) a_ = make_float4(0.f, 0.f, 0.f, 0.f);                                    \
+        *reinterpret_cast<float4*>(&sY[BUF][ROW][lq * 4]) = (RY);                                 \
+        *reinterpret_cast<float4*>(&sA[BUF][ROW][lq * 4]) = a_;                                   \
+    } while (0)
+#define SN_WG_STORE_TILES(BUF)                                  \
+    do {                                                        \
+        SN_WG_STORE_ROW(ry0, ra0, ok0, lr, BUF);                \
+        SN_WG_STORE_ROW(ry1, ra1, ok1, lr + 16, BUF);           \
+    } while (0)
+
+    f32x16w acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;
+    const int li = lane & 31, lh = lane >> 5;
+
+    SN_WG_LOAD_TILES();
+    SN_WG_STORE_TILES(0);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < steps) SN_WG_LOAD_TILES();                 // tile s + 1 -> registers (with its ok bits), under the MFMAs of tile s
+#pragma unroll
+        for (int kk = 0; kk < BR / 2; ++kk) {
+            const float a = sY[buf][2 * kk + lh][wn + li];
+            const float b = sA[buf][2 * kk + lh][wk + li];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (s + 1 < steps) SN_WG_STORE_TILES(buf ^ 1);
+        __syncthreads();
+    }
+#undef SN_WG_LOAD_ROW
+#undef SN_WG_LOAD_TILES
+#undef SN_WG_STORE_ROW
+#undef SN_WG_STORE_TILES
+    const int k = k0 + wk + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (p.slab != nullptr) p.slab[((size_t)blockIdx.z * p.Cout + n) * p.K + k] = acc[r];
+        else p.dw[(size_t)n * p.K + k] += acc[r];
+    }
+}
+
 // Wt[ci][kh][kw][co] = W[co][KH-1-kh][KW-1-kw][ci]  : the weights of the dgrad convolution (OHWI in, OHWI out)
 __global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(const float* __restrict__ w, float* __restrict__ wt,
                                                                  int Cout, int KH, int KW, int Cin) {
@@ -270,7 +412,14 @@ int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* 
         *slab_cursor += (size_t)total * elems;
     }
     const bool rec = prof != nullptr && prof->begin(st);
-    conv_wgrad_f32_kernel<<<dim3(cdiv(Cout, 64), cdiv(a.K, 64), total), 256, 0, st>>>(a);
+    static const bool fast_ok = getenv("STABNET_WGRAD_SAME") == nullptr || atoi(getenv("STABNET_WGRAD_SAME")) != 0;     // debug switch
+    const bool same = fast_ok && stride == 1 && a.Ho == H && a.Wo == W && KH == KW && (KH == 1 ? pad == 0 : (KH == 3 && pad == 1)) &&
+                      a.M % 32 == 0 && Cout % 64 == 0 && a.K % 64 == 0 && 32 / W + 1 < H &&
+                      ((long)a.M + 2L * W + 34) * Cin * 4 < (1L << 32) && ((long)32 * Cout + Cout) * 4 < (1L << 32);
+    const dim3 grid(cdiv(Cout, 64), cdiv(a.K, 64), total);
+    if (same && KH == 1) conv_wgrad_same_f32_kernel<0><<<grid, 256, 0, st>>>(a);
+    else if (same) conv_wgrad_same_f32_kernel<1><<<grid, 256, 0, st>>>(a);
+    else conv_wgrad_f32_kernel<<<grid, 256, 0, st>>>(a);
     if (rec) prof->end(st, PK_KERNEL_WGRAD, 2.0 * T * a.M * (double)a.K * Cout,
                        4.0 * T * ((double)a.M * Cout + (double)N * H * W * Cin + (double)a.K * Cout * splits), Cout, a.K, T * a.M, total);
     SN_LAUNCH_CHECK("conv_wgrad_f32_kernel");

@@ -14,6 +14,13 @@ CASES = [
     (2, 9, 16, 256, 64, 1, 1, 0, True),
     (1, 20, 28, 16, 64, 7, 2, 3, False),      # stem (wgrad only is used by the net; dgrad checked too)
     (3, 12, 12, 128, 512, 1, 1, 0, False),
+    # the stride-1 "same" wgrad kernel (scalar running bases): W = 32 (no column remainder), W = 16 < 32 (two image rows per
+    # step), W = 64, several images per split, no prologue, K and Cout of several tiles
+    (2, 16, 32, 64, 64, 3, 1, 1, True),
+    (2, 8, 16, 128, 128, 3, 1, 1, True),
+    (1, 32, 64, 64, 128, 3, 1, 1, False),
+    (8, 8, 8, 128, 192, 1, 1, 0, True),
+    (6, 8, 16, 64, 64, 3, 1, 1, True),
 ]
 
 
