@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs p) 
 // coordinates with divisions-by-loop and 64-bit addresses every step: 103 VALU instructions per 16 MFMAs, and on gfx950 every
 // VALU instruction costs ~3 cycles of f32-MFMA issue.  Requirements (host-checked): stride 1, Ho == H,
 // Wo == W, M % 32 == 0, Cout % 64 == 0, K % 64 == 0, Cin % 4 == 0, 32 / W + 1 < H.
-template <int K3>
+template <int K3, int PRO /* BN + ReLU prologue on x */>
 __global__ __launch_bounds__(256) void conv_wgrad_same_f32_kernel(const WgradArgs p) {
     constexpr int BR = 32, BT = 64;
     __shared__ __attribute__((aligned(16))) float sY[2][BR][BT];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_same_f32_kernel(const WgradArg
     const int c_t = kcol - tap * p.Cin;
     const int kh = K3 ? tap / 3 : 0, kw = K3 ? tap - kh * 3 : 0;
     const int pad = K3 ? 1 : 0;
-    const bool has_pro = pscale != nullptr;
+    constexpr bool has_pro = PRO != 0;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (has_pro) {
         sc = *reinterpret_cast<const float4*>(pscale + c_t);
@@ -275,11 +275,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_same_f32_kernel(const WgradArg
     for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
         if (s + 1 < steps) SN_WG_LOAD_TILES();                 // tile s + 1 -> registers (with its ok bits), under the MFMAs of tile s
+        // fragment reads run two MFMAs ahead of their use
+        float fa[2], fb[2], ga[2], gb[2];
 #pragma unroll
-        for (int kk = 0; kk < BR / 2; ++kk) {
-            const float a = sY[buf][2 * kk + lh][wn + li];
-            const float b = sA[buf][2 * kk + lh][wk + li];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int j = 0; j < 2; ++j) { fa[j] = sY[buf][2 * j + lh][wn + li]; fb[j] = sA[buf][2 * j + lh][wk + li]; }
+#pragma unroll
+        for (int kk = 0; kk < BR / 2; kk += 2) {
+            if (kk + 2 < BR / 2) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { ga[j] = sY[buf][2 * (kk + 2 + j) + lh][wn + li]; gb[j] = sA[buf][2 * (kk + 2 + j) + lh][wk + li]; }
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1], fb[1], acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { fa[j] = ga[j]; fb[j] = gb[j]; }
         }
         if (s + 1 < steps) SN_WG_STORE_TILES(buf ^ 1);
         __syncthreads();
@@ -417,9 +426,16 @@ int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* 
                       a.M % 32 == 0 && Cout % 64 == 0 && a.K % 64 == 0 && 32 / W + 1 < H &&
                       ((long)a.M + 2L * W + 34) * Cin * 4 < (1L << 32) && ((long)32 * Cout + Cout) * 4 < (1L << 32);
     const dim3 grid(cdiv(Cout, 64), cdiv(a.K, 64), total);
-    if (same && KH == 1) conv_wgrad_same_f32_kernel<0><<<grid, 256, 0, st>>>(a);
-    else if (same) conv_wgrad_same_f32_kernel<1><<<grid, 256, 0, st>>>(a);
-    else conv_wgrad_f32_kernel<<<grid, 256, 0, st>>>(a);
+    const bool pro = a.in_scale != nullptr;
+    if (same && KH == 1) {
+        if (pro) conv_wgrad_same_f32_kernel<0, 1><<<grid, 256, 0, st>>>(a);
+        else conv_wgrad_same_f32_kernel<0, 0><<<grid, 256, 0, st>>>(a);
+    } else if (same) {
+        if (pro) conv_wgrad_same_f32_kernel<1, 1><<<grid, 256, 0, st>>>(a);
+        else conv_wgrad_same_f32_kernel<1, 0><<<grid, 256, 0, st>>>(a);
+    } else {
+        conv_wgrad_f32_kernel<<<grid, 256, 0, st>>>(a);
+    }
     if (rec) prof->end(st, PK_KERNEL_WGRAD, 2.0 * T * a.M * (double)a.K * Cout,
                        4.0 * T * ((double)a.M * Cout + (double)N * H * W * Cin + (double)a.K * Cout * splits), Cout, a.K, T * a.M, total);
     SN_LAUNCH_CHECK("conv_wgrad_f32_kernel");
