@@ -1051,10 +1051,10 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
                                     has_add ? ad : nullptr, add_stride, xt.H, xt.W, grads + net->off_gamma + bn,
                                     grads + net->off_beta + bn, dx, partial, cf, st);
     };
-    auto bias_grad = [&](auto gin, long M, int C, long b_off) -> int {
+    auto bias_grad = [&](auto gin, long M, int C, long b_off, long b_off2 = -1) -> int {
         const float* gs[2];
         for (int t = 0; t < T; ++t) gs[t] = gin(t);
-        return launch_bias_grad_g(T, gs, M, C, grads + b_off, partial, st);
+        return launch_bias_grad_g(T, gs, M, C, grads + b_off, partial, st, b_off2 >= 0 ? grads + b_off2 : nullptr);
     };
     // dgrad of both towers: ONE launch over the [T*N, ...] pair (dy, dx, residual are pair bases)
     auto dgrad = [&](const float* dy, long pack_off, float* dx, const float* res, int H, int W, int Cin, int Cout, int K, int stride,
@@ -1096,7 +1096,8 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
         const size_t so = u.out.size, sr2 = u.r2.size, sr1 = u.r1.size, sx = u.x.size;
         auto X = [&](long off) { return [&, off](int t) -> const float* { return tw[t].ws + off; }; };
         // conv3 (1x1, bias) : input relu(bn2(r2))
-        if ((rc = bias_grad(CV(bGA, so), Mo, u.depth, u.b3)) != 0) return rc;
+        // (the projection shortcut's bias receives the same column sums of G: one reduction for both)
+        if ((rc = bias_grad(CV(bGA, so), Mo, u.depth, u.b3, u.proj ? u.b_sc : -1)) != 0) return rc;
         if ((rc = wgrad(X(u.r2.off), CV(bGA, so), u.w3, u.bn2, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0)) != 0) return rc;
         if ((rc = dgrad(bGA, net->pack_w3[ui], bT1, nullptr, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0)) != 0) return rc;
         if ((rc = bn_bwd(u.bn2, u.r2, CV(bT1, sr2), none, false, 1, V(bT1, sr2))) != 0) return rc;             // T1 = d r2
@@ -1108,7 +1109,6 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
         if ((rc = wgrad(X(u.x.off), CV(bT2, sr1), u.w1, u.bn_pre, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 0)) != 0) return rc;
         if ((rc = dgrad(bT2, net->pack_w1[ui], bT3, nullptr, u.x.H, u.x.W, u.cin, u.dbn, 1, 1, 0)) != 0) return rc;
         if (u.proj) {   // projection shortcut conv1x1(preact) + bias: d preact += dgrad(G)
-            if ((rc = bias_grad(CV(bGA, so), Mo, u.depth, u.b_sc)) != 0) return rc;
             if ((rc = wgrad(X(u.x.off), CV(bGA, so), u.w_sc, u.bn_pre, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 0)) != 0) return rc;
             if ((rc = dgrad(bGA, net->pack_sc[ui], bT3, bT3, u.x.H, u.x.W, u.cin, u.depth, 1, 1, 0)) != 0) return rc;
             if ((rc = bn_bwd(u.bn_pre, u.x, CV(bT3, sx), none, false, 1, V(bGB, sx))) != 0) return rc;

@@ -19,7 +19,8 @@ int launch_bn_relu_bwd_g(int groups, const float* const* x, const float* const* 
                          const float* const* shift, const float* const* mean, const float* const* invstd, const float* gamma,
                          long M, int C, const float* const* addend, int add_stride, int H, int W, float* d_gamma, float* d_beta,
                          float* const* d_x, float* partial, float* const* coef, hipStream_t st);
-int launch_bias_grad_g(int groups, const float* const* g, long M, int C, float* d_bias, float* partial, hipStream_t st);
+int launch_bias_grad_g(int groups, const float* const* g, long M, int C, float* d_bias, float* partial, hipStream_t st,
+                       float* d_bias2 = nullptr);      // d_bias2: a second bias fed by the same gradient (+= the same sums)
 int launch_bn_stats(const float* x, long M, int C, const float* gamma, const float* beta, float eps, float decay,
                     float* scale, float* shift, float* save_mean, float* save_invstd, float* mov_mean, float* mov_var,
                     float* partial, hipStream_t st);

@@ -150,13 +150,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     }
 }
 
+// (d_bias2, optional: a second bias fed by the same gradient -- conv3 and the projection shortcut of a unit both add into its output)
 __global__ __launch_bounds__(1024) void bias_grad_finalize_kernel(const float* __restrict__ partial, int chunks, int groups, int C,
-                                                                 float* __restrict__ d_bias) {
+                                                                 float* __restrict__ d_bias, float* __restrict__ d_bias2) {
     const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH), lane = threadIdx.x / FIN_CH;
     for (int gi = 0; gi < groups; ++gi) {
         double s, unused;
         combine_partials(partial + (size_t)gi * chunks * 2 * C, chunks, C, c, lane, s, unused);
-        if (lane == 0 && c < C) d_bias[c] += (float)s;
+        if (lane == 0 && c < C) {
+            d_bias[c] += (float)s;
+            if (d_bias2 != nullptr) d_bias2[c] += (float)s;
+        }
         __syncthreads();
     }
 }
@@ -485,7 +489,7 @@ int launch_bn_relu_bwd_g(int groups, const float* const* x, const float* const* 
     return STABNET_OK;
 }
 
-int launch_bias_grad_g(int groups, const float* const* g, long M, int C, float* d_bias, float* partial, hipStream_t st) {
+int launch_bias_grad_g(int groups, const float* const* g, long M, int C, float* d_bias, float* partial, hipStream_t st, float* d_bias2) {
     SN_REQUIRE(C % 4 == 0 && (groups == 1 || groups == 2), "bias_grad: C %% 4 != 0 or bad group count");
     long rpc;
     const int chunks = reduce_chunks(M, C, rpc);
@@ -493,7 +497,7 @@ int launch_bias_grad_g(int groups, const float* const* g, long M, int C, float* 
     for (int i = 0; i < groups; ++i) G.g[i] = g[i];
     col_reduce_kernel<2><<<dim3(cdiv(C, 64), chunks, groups), 256, 0, st>>>(G, M, C, rpc, partial);
     SN_LAUNCH_CHECK("col_reduce_kernel<2>");
-    bias_grad_finalize_kernel<<<cdiv(C, FIN_CH), FIN_CH * FIN_LANES, 0, st>>>(partial, chunks, groups, C, d_bias);
+    bias_grad_finalize_kernel<<<cdiv(C, FIN_CH), FIN_CH * FIN_LANES, 0, st>>>(partial, chunks, groups, C, d_bias, d_bias2);
     SN_LAUNCH_CHECK("bias_grad_finalize_kernel");
     return STABNET_OK;
 }
@@ -514,7 +518,7 @@ int launch_bn_relu_bwd(const float* x, const float* g, const float* scale, const
 }
 
 int launch_bias_grad(const float* g, long M, int C, float* d_bias, float* partial, hipStream_t st) {
-    return launch_bias_grad_g(1, &g, M, C, d_bias, partial, st);
+    return launch_bias_grad_g(1, &g, M, C, d_bias, partial, st, nullptr);
 }
 
 int launch_max_pool_bwd(const unsigned char* argmax, const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo,
