@@ -319,7 +319,7 @@ int conv_launch_pair(const ConvArgs& a, const ConvPair& pr, hipStream_t st, Prof
     int rc;
     if (bk32) rc = mode == 0 ? launch_pair_one<32, 0>(a, pr, st) : launch_pair_one<32, 1>(a, pr, st);
     else rc = mode == 0 ? launch_pair_one<16, 0>(a, pr, st) : launch_pair_one<16, 1>(a, pr, st);
-    if (rec) prof->end(st, PK_KERNEL_CONV_BASE + mode * 6 + T64x64 * 2 + (bk32 ? 1 : 0), 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
+    if (rec) prof->end(st, PK_KERNEL_CONV_PAIR + mode * 2 + (bk32 ? 1 : 0), 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
                        4.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.K * a.Cout + (double)a.M * a.Cout * a.splitk),
                        a.M, a.Cout, a.K, a.splitk);
     if (rc) return rc;

@@ -436,7 +436,7 @@ int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* 
     } else {
         conv_wgrad_f32_kernel<<<grid, 256, 0, st>>>(a);
     }
-    if (rec) prof->end(st, PK_KERNEL_WGRAD, 2.0 * T * a.M * (double)a.K * Cout,
+    if (rec) prof->end(st, same ? PK_KERNEL_WGRAD_SAME + 2 * (KH == 3 ? 1 : 0) + (pro ? 1 : 0) : PK_KERNEL_WGRAD, 2.0 * T * a.M * (double)a.K * Cout,
                        4.0 * T * ((double)a.M * Cout + (double)N * H * W * Cin + (double)a.K * Cout * splits), Cout, a.K, T * a.M, total);
     SN_LAUNCH_CHECK("conv_wgrad_f32_kernel");
     if (total > 1 && table == nullptr) return wgrad_reduce_flush(dw_base, local, st);

@@ -585,6 +585,16 @@ const char* stabnet_prof_kind_name(int kind) {
         case PK_KERNEL_WGRAD: return "conv_wgrad_f32_kernel";
         default: break;
     }
+    if (kind >= PK_KERNEL_WGRAD_SAME && kind < PK_KERNEL_WGRAD_SAME + 4) {
+        static const char* const names[4] = {"conv_wgrad_same_f32_kernel<0, 0>", "conv_wgrad_same_f32_kernel<0, 1>",
+                                             "conv_wgrad_same_f32_kernel<1, 0>", "conv_wgrad_same_f32_kernel<1, 1>"};
+        return names[kind - PK_KERNEL_WGRAD_SAME];
+    }
+    if (kind >= PK_KERNEL_CONV_PAIR && kind < PK_KERNEL_CONV_PAIR + 4) {
+        static const char* const names[4] = {"conv_igemm_f32_pair_kernel<64, 64, 16, 32, 32, 0>", "conv_igemm_f32_pair_kernel<64, 64, 32, 32, 32, 0>",
+                                             "conv_igemm_f32_pair_kernel<64, 64, 16, 32, 32, 1>", "conv_igemm_f32_pair_kernel<64, 64, 32, 32, 32, 1>"};
+        return names[kind - PK_KERNEL_CONV_PAIR];
+    }
     // names as rocprofv3 prints the template instantiation <MODE, BF16>
     if (kind == PK_KERNEL_CONV_RING) return "conv_ring_f32_kernel<0, 0>";
     if (kind == PK_KERNEL_CONV_RING + 1) return "conv_ring_f32_kernel<1, 0>";

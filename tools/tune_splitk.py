@@ -31,7 +31,7 @@ def key_of(name, shp):
         return (M, N, K, 3, 1)
     if name.startswith("conv_ring_f32_kernel<2"):
         return (M, N, K, 7, 1)
-    mode = int(name.split(",")[5])
+    mode = int(name.split(",")[5].strip(" >"))          # conv_igemm_f32_kernel<BM, BN, BK, WM, WN, MODE, ...> and ..._pair_kernel<..., MODE>
     kh = 1 if mode == 0 else (7 if K == 784 else 3)
     return (M, N, K, kh, 0)
 
