@@ -211,13 +211,14 @@ static int launch_one(const ConvArgs& a, hipStream_t st) {
 // LDS-DMA ring kernel (conv_ring_kernel.h): no A-operand prologue, stride-free addressing, Cin % 32 == 0, 64x64 tile.
 static int g_ring = -1;
 
-static bool ring_eligible(const ConvArgs& a, int tile) {
+static bool ring_eligible(const ConvArgs& a, int tile, bool has_prologue) {
     if (g_ring < 0) {
         g_ring = env_int("STABNET_CONV_RING", 1);
     }
     if (a.rowrun) return true;                              // the row-run A operand exists only in the ring kernel
-    return g_ring && tile == T64x64 && a.in_scale == nullptr && a.up == 1 && a.Cin % 32 == 0 && !g_force_bk16;
+    return g_ring && tile == T64x64 && !has_prologue && a.up == 1 && a.Cin % 32 == 0 && !g_force_bk16;
 }
+static bool ring_eligible(const ConvArgs& a, int tile) { return ring_eligible(a, tile, a.in_scale != nullptr); }
 
 static int g_ring_wgs = 0;        // resident workgroups of the ring kernel on this device (3 per CU: 48 KiB LDS each)
 
@@ -290,9 +291,8 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands
 bool conv_pair_supported(const ConvArgs& a) {
     int splitk_unused = 1;
     const int t = pick_tile(a, splitk_unused);
-    ConvArgs probe = a;                                    // (at plan time the prologue pointers are not set yet)
-    if (a.in_scale_expected && probe.in_scale == nullptr) probe.in_scale = probe.in_shift = reinterpret_cast<const float*>(&probe);
-    return t == T64x64 && !ring_eligible(probe, t) && a.up == 1 && !a.rowrun && (a.x_ld == 0 || a.x_ld == a.Cin);
+    const bool pro = a.in_scale != nullptr || a.in_scale_expected;     // (at plan time the prologue pointers are not bound yet)
+    return t == T64x64 && !ring_eligible(a, t, pro) && a.up == 1 && !a.rowrun && (a.x_ld == 0 || a.x_ld == a.Cin);
 }
 
 template <int BK, int MODE>
