@@ -146,6 +146,46 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, co
     }
 }
 
+// The same product for 9..16 rows (the siamese pair of a training step): the activations [M][K] are staged ONCE per workgroup in LDS
+// (<= 128 KiB) and every wave then streams whole weight rows against them -- in fc_kernel each wave re-reads all M rows of x from
+// L2 per weight row (17 load instructions per 4 weight floats), which left the 16.8 MB fc_1 at 0.5 TB/s.  Per output element the
+// arithmetic (and its order) is that of fc_kernel: bitwise the same result.
+__global__ __launch_bounds__(256) void fc_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ y, int M, int K, int Nout,
+                                                     int relu) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];          // [M][K]
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid * 4; i < M * K; i += 256 * 4) *reinterpret_cast<float4*>(xs + i) = *reinterpret_cast<const float4*>(x + i);
+    __syncthreads();
+    const int waves = gridDim.x * 4;
+    for (int n = blockIdx.x * 4 + (tid >> 6); n < Nout; n += waves) {
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* wr = w + (size_t)n * K;
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i < M) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xs + i * K + k);
+                    acc[i] += ((xv.x * wv.x + xv.y * wv.y) + xv.z * wv.z) + xv.w * wv.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = acc[i];
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0 && i < M) {
+                v += (b != nullptr) ? b[n] : 0.f;
+                if (relu) v = fmaxf(v, 0.f);
+                y[(size_t)i * Nout + n] = v;
+            }
+        }
+    }
+}
+
 // OHWI [Cout][KH][KW][CinPad] -> row-run layout [Cout][KH][Rp], Rp = roundup(KW*Cin, 32): element kw*Cin + c, zeros behind.
 __global__ __launch_bounds__(256) void stem_repack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int KH,
                                                           int KW, int CinPad, int Cin, int Rp) {
@@ -228,7 +268,23 @@ int launch_fc(const float* x, const float* w, const float* b, float* y, int M, i
               hipStream_t st) {
     SN_REQUIRE(K % 4 == 0, "fc: K %% 4 != 0");
     int m0 = 0;
-    for (; M - m0 > 8; m0 += 16) {          // 9..16 rows left: one pass (the siamese pair at 8 samples per tower)
+    if (M > 8 && M <= 16 && (size_t)M * K * sizeof(float) <= 128 * 1024) {
+        // the siamese pair at <= 8 samples per tower: activations staged in LDS, one workgroup per CU
+        static bool configured = false;
+        const size_t lds = (size_t)M * K * sizeof(float);
+        if (!configured) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) {
+                stabnet_set_error("fc: hipFuncSetAttribute(128 KiB LDS) failed: %s", hipGetErrorString(e));
+                return STABNET_ERR_LAUNCH;
+            }
+            configured = true;
+        }
+        fc_lds_kernel<<<std::min(256, cdiv(Nout, 4)), 256, lds, st>>>(x, w, b, y, M, K, Nout, relu);
+        SN_LAUNCH_CHECK("fc_lds_kernel");
+        return STABNET_OK;
+    }
+    for (; M - m0 > 8; m0 += 16) {          // 9..16 rows left: one pass
         fc_kernel<16><<<cdiv(Nout, 4), 256, 0, st>>>(x, w, b, y, M, K, Nout, relu, m0);
         SN_LAUNCH_CHECK("fc_kernel");
     }

@@ -284,49 +284,70 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ 
 }
 
 // FC backward.  dyr = dy * (y > 0) when relu.  dW[n][k] += sum_m dyr[m][n] x[m][k];  db[n] += sum_m dyr[m][n].
+// One thread per (n, 4 consecutive k): the x rows are L2-hot (<= 128 KB), dW is read-modify-written 16 B per lane.
 __global__ __launch_bounds__(256) void fc_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                        const float* __restrict__ dy, int M, int K, int Nout, int relu,
                                                        float* __restrict__ dW, float* __restrict__ db) {
     const int n = blockIdx.y;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    float acc = 0.f, bacc = 0.f;
+    const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bacc = 0.f;
     for (int m = 0; m < M; ++m) {
         float d = dy[(size_t)m * Nout + n];
         if (relu && !(y[(size_t)m * Nout + n] > 0.f)) d = 0.f;
         bacc += d;
-        if (k < K) acc += d * x[(size_t)m * K + k];
+        if (k < K) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * K + k);
+            acc.x += d * xv.x; acc.y += d * xv.y; acc.z += d * xv.z; acc.w += d * xv.w;
+        }
     }
-    if (k < K) dW[(size_t)n * K + k] += acc;
+    if (k < K) {
+        float4* p = reinterpret_cast<float4*>(dW + (size_t)n * K + k);
+        float4 o = *p;
+        o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+        *p = o;
+    }
     if (k == 0) db[n] += bacc;
 }
 
 // dx[m][k] = sum_n dyr[m][n] W[n][k]: the n range is split over blockIdx.y into partial sums part[split][m][k] (plain
-// stores), which fc_bwd_x_reduce_kernel adds in split order -- no atomics, reproducible.
+// stores), which fc_bwd_x_reduce_kernel adds in split order -- no atomics, reproducible.  One thread per 4 consecutive k for up
+// to 16 rows m at once (the siamese pair): each weight row is read ONCE, 16 B per lane, eight rows in flight; the block's
+// [M][n_per_block] slice of dyr is staged in LDS (uniform reads).  M > 16: passes of 16 rows.
+constexpr int FCX_NPB = 32;
 __global__ __launch_bounds__(256) void fc_bwd_x_kernel(const float* __restrict__ w, const float* __restrict__ y,
                                                        const float* __restrict__ dy, int M, int K, int Nout, int relu,
                                                        int n_per_block, float* __restrict__ part) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
+    __shared__ float sd[16][FCX_NPB];
+    const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int nb = blockIdx.y * n_per_block, ne = min(Nout, nb + n_per_block);
-    for (int m0 = 0; m0 < M; m0 += 8) {
-        float acc[8];
+    for (int m0 = 0; m0 < M; m0 += 16) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 16 * FCX_NPB; i += 256) {
+            const int m = m0 + i / FCX_NPB, n = nb + i % FCX_NPB;
+            float d = 0.f;
+            if (m < M && n < ne) {
+                d = dy[(size_t)m * Nout + n];
+                if (relu && !(y[(size_t)m * Nout + n] > 0.f)) d = 0.f;
+            }
+            sd[i / FCX_NPB][i % FCX_NPB] = d;
+        }
+        __syncthreads();
+        if (k >= K) continue;
+        float4 acc[16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int n = nb; n < ne; ++n) {
-            const float wv = w[(size_t)n * K + k];
+            const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)n * K + k);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = m0 + i;
-                if (m < M) {
-                    float d = dy[(size_t)m * Nout + n];
-                    if (relu && !(y[(size_t)m * Nout + n] > 0.f)) d = 0.f;
-                    acc[i] += d * wv;
-                }
+            for (int i = 0; i < 16; ++i) {
+                const float d = sd[i][n - nb];
+                acc[i].x += d * wv.x; acc[i].y += d * wv.y; acc[i].z += d * wv.z; acc[i].w += d * wv.w;
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (m0 + i < M) part[((size_t)blockIdx.y * M + m0 + i) * K + k] = acc[i];
+        for (int i = 0; i < 16; ++i)
+            if (m0 + i < M) *reinterpret_cast<float4*>(part + ((size_t)blockIdx.y * M + m0 + i) * K + k) = acc[i];
     }
 }
 __global__ __launch_bounds__(256) void fc_bwd_x_reduce_kernel(const float* __restrict__ part, int splits, long MK,
@@ -546,13 +567,14 @@ int launch_gap_bwd(const float* dg, int N, int HW, int C, float* da, hipStream_t
 
 int launch_fc_bwd(const float* x, const float* w, const float* y, const float* dy, int M, int K, int Nout, int relu,
                   float* dW, float* db, float* dx, float* scratch, size_t scratch_floats, hipStream_t st) {
-    fc_bwd_w_kernel<<<dim3(cdiv(K, 256), Nout), 256, 0, st>>>(x, y, dy, M, K, Nout, relu, dW, db);
+    SN_REQUIRE(K % 4 == 0, "fc_bwd: K %% 4 != 0");
+    fc_bwd_w_kernel<<<dim3(cdiv(K, 1024), Nout), 256, 0, st>>>(x, y, dy, M, K, Nout, relu, dW, db);
     SN_LAUNCH_CHECK("fc_bwd_w_kernel");
     if (dx != nullptr) {
-        const int npb = 32, splits = cdiv(Nout, npb);
+        const int npb = FCX_NPB, splits = cdiv(Nout, npb);
         SN_REQUIRE(scratch != nullptr && scratch_floats >= (size_t)splits * M * K, "fc_bwd: scratch of %zu floats needed",
                    (size_t)splits * M * K);
-        fc_bwd_x_kernel<<<dim3(cdiv(K, 256), splits), 256, 0, st>>>(w, y, dy, M, K, Nout, relu, npb, scratch);
+        fc_bwd_x_kernel<<<dim3(cdiv(K, 1024), splits), 256, 0, st>>>(w, y, dy, M, K, Nout, relu, npb, scratch);
         SN_LAUNCH_CHECK("fc_bwd_x_kernel");
         fc_bwd_x_reduce_kernel<<<cdiv((long)M * K, 256), 256, 0, st>>>(scratch, splits, (long)M * K, dx);
         SN_LAUNCH_CHECK("fc_bwd_x_reduce_kernel");
