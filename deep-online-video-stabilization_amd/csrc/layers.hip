@@ -163,13 +163,24 @@ __global__ __launch_bounds__(256) void fc_lds_kernel(const float* __restrict__ x
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         const float* wr = w + (size_t)n * K;
-        for (int k = lane * 4; k < K; k += 256) {
-            const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+        for (int kb = 0; kb < K; kb += 8 * 256) {          // eight 16-B loads of the weight row in flight per lane, then the products
+            float4 wv[8];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (i < M) {
-                    const float4 xv = *reinterpret_cast<const float4*>(xs + i * K + k);
-                    acc[i] += ((xv.x * wv.x + xv.y * wv.y) + xv.z * wv.z) + xv.w * wv.w;
+            for (int j = 0; j < 8; ++j) {
+                const int k = kb + j * 256 + lane * 4;
+                wv[j] = (k < K) ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = kb + j * 256 + lane * 4;
+                if (k < K) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if (i < M) {
+                            const float4 xv = *reinterpret_cast<const float4*>(xs + i * K + k);
+                            acc[i] += ((xv.x * wv[j].x + xv.y * wv[j].y) + xv.z * wv[j].z) + xv.w * wv[j].w;
+                        }
+                    }
                 }
             }
         }
