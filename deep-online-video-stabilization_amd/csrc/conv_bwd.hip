@@ -374,9 +374,44 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ g
     *d = o;
 }
 
+// The same reduction with the slab list of an element cut into FOUR contiguous runs summed by four threads and combined in run
+// order through LDS (still one fixed order): a layer of 64 x 576 weights has 226 slabs of 9 216 float4 -- 36 blocks walking 226
+// dependent-latency steps each in the flat form (the launch ran at 2.2 TB/s); here 144 blocks walk 57.  Needs every entry's
+// element count to be a multiple of 256 (64 float4 columns per block never straddle two entries).
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(float* __restrict__ grads, const WgradReduceTable t) {
+    __shared__ float4 sh[4][64];
+    const long q0 = (long)blockIdx.x * 64;
+    int lo = 0, hi = t.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.prefix[mid] <= q0) lo = mid; else hi = mid - 1;
+    }
+    const WgradReduceEntry e = t.e[lo];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long i = (q0 - t.prefix[lo] + col) * 4;
+    const int per = (e.splits + 3) >> 2;
+    const int z0 = min(e.splits, grp * per), z1 = min(e.splits, z0 + per);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    slab_sum(e.slab[0] + i + (size_t)z0 * e.elems, z1 - z0, e.elems, acc);
+    if (e.slab[1] != nullptr) slab_sum(e.slab[1] + i + (size_t)z0 * e.elems, z1 - z0, e.elems, acc);
+    sh[grp][col] = acc;
+    __syncthreads();
+    if (grp == 0) {
+        float4 s = sh[0][col];
+        for (int g = 1; g < 4; ++g) { const float4 u = sh[g][col]; s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w; }
+        float4* d = reinterpret_cast<float4*>(grads + e.dw_off + i);
+        float4 o = *d;
+        o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+        *d = o;
+    }
+}
+
 int wgrad_reduce_flush(float* grads, WgradReduceTable& t, hipStream_t st) {
     if (t.n == 0) return STABNET_OK;
-    wgrad_reduce_kernel<<<cdiv(t.prefix[t.n], 256), 256, 0, st>>>(grads, t);
+    bool by4 = true;
+    for (int i = 0; i < t.n; ++i) by4 = by4 && t.e[i].elems % 256 == 0 && t.e[i].slab[1] == nullptr;
+    if (by4) wgrad_reduce4_kernel<<<(unsigned)(t.prefix[t.n] / 64), 256, 0, st>>>(grads, t);
+    else wgrad_reduce_kernel<<<cdiv(t.prefix[t.n], 256), 256, 0, st>>>(grads, t);
     SN_LAUNCH_CHECK("wgrad_reduce_kernel");
     t.n = 0; t.prefix[0] = 0;
     return STABNET_OK;
