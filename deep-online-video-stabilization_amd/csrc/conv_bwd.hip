@@ -307,15 +307,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_same_f32_kernel(const WgradArg
 }
 
 // Wt[ci][kh][kw][co] = W[co][KH-1-kh][KW-1-kw][ci]  : the weights of the dgrad convolution (OHWI in, OHWI out)
+// kperm (3x3 filters of stride-2 layers): the tap rows are stored in the order (1, 0, 2), see conv_igemm_body.h (MODE 2).
+__device__ __forceinline__ int dgrad_tap_row(int kh_stored, int kperm) {
+    return kperm ? (kh_stored == 0 ? 1 : (kh_stored == 1 ? 0 : 2)) : kh_stored;
+}
 __global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(const float* __restrict__ w, float* __restrict__ wt,
-                                                                 int Cout, int KH, int KW, int Cin) {
+                                                                 int Cout, int KH, int KW, int Cin, int kperm) {
     const long total = (long)Cout * KH * KW * Cin;
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     if (q >= total) return;
     const int co = (int)(q % Cout);
     long r = q / Cout;
     const int kw = (int)(r % KW); r /= KW;
-    const int kh = (int)(r % KH);
+    const int kh = dgrad_tap_row((int)(r % KH), kperm);
     const int ci = (int)(r / KH);
     wt[q] = w[(((size_t)co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * Cin + ci];
 }
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(256) void pack_dgrad_weights_all_kernel(const float
     const int co = (int)(e % d.Cout);
     long r = e / d.Cout;
     const int kw = (int)(r % d.K); r /= d.K;
-    const int kh = (int)(r % d.K);
+    const int kh = dgrad_tap_row((int)(r % d.K), d.kperm);
     const int ci = (int)(r / d.K);
     wt[q] = params[d.w_off + (((size_t)co * d.K + (d.K - 1 - kh)) * d.K + (d.K - 1 - kw)) * d.Cin + ci];
 }
@@ -522,10 +526,11 @@ __global__ __launch_bounds__(256) void pack_dgrad_weights_tiled_kernel(const flo
     long r = (q - t.prefix[lo]) >> 10;                    // tile index inside the layer: co tile fastest, then tap, then ci tile
     const int cot = (int)(r % (d.Cout >> 5)); r /= (d.Cout >> 5);
     const int kw = (int)(r % d.K); r /= d.K;
-    const int kh = (int)(r % d.K);
+    const int kh = (int)(r % d.K);                         // stored tap row; its source row:
+    const int khs = dgrad_tap_row(kh, d.kperm);
     const int cit = (int)(r / d.K);
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const float* src = params + d.w_off + ((size_t)(d.K - 1 - kh) * d.K + (d.K - 1 - kw)) * d.Cin + cit * 32 + lx;
+    const float* src = params + d.w_off + ((size_t)(d.K - 1 - khs) * d.K + (d.K - 1 - kw)) * d.Cin + cit * 32 + lx;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int co = cot * 32 + ly + 8 * i;
@@ -554,9 +559,9 @@ int pack_dgrad_weights_all(const float* params, float* wt, const PackTable& t, h
     return STABNET_OK;
 }
 
-int pack_dgrad_weights(const float* w, float* wt, int Cout, int KH, int KW, int Cin, hipStream_t st) {
+int pack_dgrad_weights(const float* w, float* wt, int Cout, int KH, int KW, int Cin, int kperm, hipStream_t st) {
     const long total = (long)Cout * KH * KW * Cin;
-    pack_dgrad_weights_kernel<<<cdiv(total, 256), 256, 0, st>>>(w, wt, Cout, KH, KW, Cin);
+    pack_dgrad_weights_kernel<<<cdiv(total, 256), 256, 0, st>>>(w, wt, Cout, KH, KW, Cin, kperm);
     SN_LAUNCH_CHECK("pack_dgrad_weights_kernel");
     return STABNET_OK;
 }
@@ -621,7 +626,7 @@ int stabnet_conv2d_dgrad(const float* dy, const float* w_ohwi, float* dx, const 
     SN_REQUIRE(workspace_bytes >= stabnet_conv2d_dgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad),
                "conv2d_dgrad: workspace too small");
     float* wt = static_cast<float*>(workspace);
-    int rc = pack_dgrad_weights(w_ohwi, wt, Cout, KH, KW, Cin, (hipStream_t)stream);
+    int rc = pack_dgrad_weights(w_ohwi, wt, Cout, KH, KW, Cin, dgrad_kperm(KH, KW, stride), (hipStream_t)stream);
     if (rc) return rc;
     const size_t off = (wbytes + 255) & ~(size_t)255;
     return dgrad_launch(dy, wt, dx, residual, N, H, W, Cin, Cout, KH, KW, stride, pad,

@@ -25,8 +25,23 @@
 
     const int cin_steps = p.Cin / BK;
     const int total_steps = p.KH * p.KW * cin_steps;
-    const int ks_begin = tile.z * p.steps_per_split;
-    const int ks_end = min(total_steps, ks_begin + p.steps_per_split);
+    const int ks_begin0 = tile.z * p.steps_per_split;
+    const int ks_end0 = min(total_steps, ks_begin0 + p.steps_per_split);
+    int ks_b = ks_begin0, ks_e = ks_end0;
+    // MODE 2 = dgrad of a stride-2 conv: the input is dY dilated by 2, so a tap row kh only meets real samples on output rows of
+    // one parity.  For 3x3 / stride 2 the re-packed weights keep their tap rows in the order (1, 0, 2) (pack_dgrad_weights*,
+    // `kperm`): the rows valid for a tile whose 64 pixels lie in ONE output row are then one contiguous run of K steps -- the
+    // first third (kh = 1) or the last two thirds (kh = 0, 2) -- and the rest is skipped instead of multiplied by zeros.
+    const bool kperm = MODE == 2 && p.KH == 3 && p.KW == 3 && p.up == 2;
+    if constexpr (MODE == 2) {
+        if (kperm && p.Wo % BM == 0) {
+            const int oy = (m0 / p.Wo) % p.Ho;
+            const int third = p.KW * cin_steps;
+            if ((p.pad - oy) & 1) ks_e = min(ks_e, third);
+            else ks_b = max(ks_b, third);
+        }
+    }
+    const int ks_begin = ks_b, ks_end = ks_e;
 
     // ---- loader mapping: thread -> (row within pass, float4 within the BK slice).
     // The K loop must stay (almost) free of vector ALU work: on gfx950 every VALU instruction costs ~3 cycles of
@@ -101,7 +116,7 @@
     for (int ps = 0; ps < A_PASSES; ++ps) okv[ps] = true;
     auto load_tiles = [&]() {
         if (MODE == 2) {
-            const int kh = l_kh, kw = l_kw, c0 = l_c0;
+            const int kh = kperm ? (l_kh == 0 ? 1 : (l_kh == 1 ? 0 : 2)) : l_kh, kw = l_kw, c0 = l_c0;
 #pragma unroll
             for (int ps = 0; ps < A_PASSES; ++ps) {
                 int iy = a_iy0[ps] + kh, ix = a_ix0[ps] + kw;

@@ -418,9 +418,9 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
     {   // dgrad weight re-pack table, in the order run_backward consumes it
         PackTable& t = net->packs;
         t.n = 0; t.prefix[0] = 0;
-        auto add = [&](long w_off, int Cout, int K, int Cin) -> long {
+        auto add = [&](long w_off, int Cout, int K, int Cin, int stride = 1) -> long {
             const long off = t.prefix[t.n];
-            t.d[t.n] = {w_off, Cout, K, Cin, 0};
+            t.d[t.n] = {w_off, Cout, K, Cin, dgrad_kperm(K, K, stride)};
             t.prefix[t.n + 1] = off + (long)Cout * K * K * Cin;
             ++t.n;
             return off;
@@ -428,7 +428,7 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
         for (size_t ui = 0; ui < net->units.size() && ui < 16; ++ui) {
             const UnitInfo& u = net->units[ui];
             net->pack_w3[ui] = add(u.w3, u.depth, 1, u.dbn);
-            net->pack_w2[ui] = add(u.w2, u.dbn, 3, u.dbn);
+            net->pack_w2[ui] = add(u.w2, u.dbn, 3, u.dbn, u.stride);
             net->pack_w1[ui] = add(u.w1, u.dbn, 1, u.cin);
             net->pack_sc[ui] = u.proj ? add(u.w_sc, u.depth, 1, u.cin) : -1;
         }

@@ -54,10 +54,13 @@ int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* 
 int wgrad_launch(const float* x, const float* dy, float* dw_base, long dw_off, const float* in_scale, const float* in_shift,
                  int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* slab_base,
                  size_t* slab_cursor, size_t slab_capacity, WgradReduceTable* table, hipStream_t st, Prof* prof);
-int pack_dgrad_weights(const float* w, float* wt, int Cout, int KH, int KW, int Cin, hipStream_t st);
+// kperm: tap rows stored in the order (1, 0, 2) -- what the dgrad kernel expects for 3x3 filters of stride-2 layers (it skips the
+// tap rows that only meet the zeros of the dilated dY); dgrad_kperm() says when.
+inline int dgrad_kperm(int KH, int KW, int stride) { return (KH == 3 && KW == 3 && stride == 2) ? 1 : 0; }
+int pack_dgrad_weights(const float* w, float* wt, int Cout, int KH, int KW, int Cin, int kperm, hipStream_t st);
 // every dgrad weight tensor of a net, re-packed by one launch: layer i = params[w_off ...] OHWI [Cout][K][K][Cin] ->
 // wt[prefix[i] ...] as [Cin][K][K][Cout] with both filter axes flipped
-struct PackDesc { long w_off; int Cout, K, Cin, pad_; };
+struct PackDesc { long w_off; int Cout, K, Cin, kperm; };
 struct PackTable { PackDesc d[56]; long prefix[57]; int n; };
 int pack_dgrad_weights_all(const float* params, float* wt, const PackTable& t, hipStream_t st);
 int dgrad_launch(const float* dy, const float* wt, float* dx, const float* residual, int N, int H, int W, int Cin,

@@ -21,6 +21,9 @@ CASES = [
     (1, 32, 64, 64, 128, 3, 1, 1, False),
     (8, 8, 8, 128, 192, 1, 1, 0, True),
     (6, 8, 16, 64, 64, 3, 1, 1, True),
+    # stride-2 dgrad with whole output rows per tile (dx width % 64 == 0): the tap rows that only meet the dilation's zeros are skipped
+    (2, 16, 128, 64, 64, 3, 2, 1, True),
+    (1, 8, 64, 128, 128, 3, 2, 1, False),
 ]
 
 
