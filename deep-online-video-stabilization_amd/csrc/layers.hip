@@ -122,14 +122,27 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, co
 #pragma unroll
     for (int i = 0; i < MR; ++i) acc[i] = 0.f;
     const float* wr = w + (size_t)n * K;
-    for (int k = lane * 4; k < K; k += 256) {
-        const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+    // the weight row is the only HBM stream of this kernel: its (up to eight) 16-B loads per lane are issued together, not one
+    // per loop trip (at batch 1 the trips were eight dependent HBM latencies); the sums keep their order
+    for (int kb = 0; kb < K; kb += 8 * 256) {
+        float4 wv[8];
 #pragma unroll
-        for (int i = 0; i < MR; ++i) {
-            const int m = m_begin + i;
-            if (m < M) {
-                const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * K + k);
-                acc[i] += ((xv.x * wv.x + xv.y * wv.y) + xv.z * wv.z) + xv.w * wv.w;
+        for (int j = 0; j < 8; ++j) {
+            const int k = kb + j * 256 + lane * 4;
+            wv[j] = (k < K) ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kb + j * 256 + lane * 4;
+            if (k < K) {
+#pragma unroll
+                for (int i = 0; i < MR; ++i) {
+                    const int m = m_begin + i;
+                    if (m < M) {
+                        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * K + k);
+                        acc[i] += ((xv.x * wv[j].x + xv.y * wv[j].y) + xv.z * wv[j].z) + xv.w * wv[j].w;
+                    }
+                }
             }
         }
     }
