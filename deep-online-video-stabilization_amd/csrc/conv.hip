@@ -216,6 +216,10 @@ static bool ring_eligible(const ConvArgs& a, int tile, bool has_prologue) {
         g_ring = env_int("STABNET_CONV_RING", 1);
     }
     if (a.rowrun) return true;                              // the row-run A operand exists only in the ring kernel
+    // two-step tiles (1x1, K = 64) with a plain epilogue are 2 us faster per launch on the register-staged kernel (more resident
+    // workgroups to overlap the 16 KB epilogues: 33.4 vs 35.3 us at M = 57 600, N = 256); the merged shortcut|conv1 launch stays here
+    static const int lowk = env_int("STABNET_CONV_LOWK_IGEMM", 1);
+    if (lowk && a.KH == 1 && a.KW == 1 && a.Cin == 64 && a.x_ld == a.Cin && a.out_floor == nullptr) return false;
     return g_ring && tile == T64x64 && !has_prologue && a.up == 1 && a.Cin % 32 == 0 && !g_force_bk16;
 }
 static bool ring_eligible(const ConvArgs& a, int tile) { return ring_eligible(a, tile, a.in_scale != nullptr); }
