@@ -195,10 +195,13 @@ static thread_local int g_bf16_operands = 0;      // set by conv_launch for the 
 
 template <int BM, int BN, int BK, int WM, int WN, int MODE>
 static int launch_one_t(const ConvArgs& a, hipStream_t st) {
-    static const int nbuf = env_int("STABNET_CONV_NBUF", 2);
+    static const int nbuf = env_int("STABNET_CONV_NBUF", 0);          // 0: the rule below; 1 / 2: forced
     if constexpr (BM == 64 && BN == 64 && BK == 32)           // the bf16-operand variant exists for the inference tile only
         if (g_bf16_operands) return launch_one_nb<BM, BN, BK, WM, WN, MODE, 2, 1>(a, st);
-    return nbuf == 1 ? launch_one_nb<BM, BN, BK, WM, WN, MODE, 1>(a, st) : launch_one_nb<BM, BN, BK, WM, WN, MODE, 2>(a, st);
+    // 1x1 launches over the large maps (block 1 at 720p: M = 57 600) are bandwidth / epilogue shaped: ONE LDS stage (18 KB, twice
+    // the resident workgroups) beats the double-buffered loop there (30.4 -> 28.8 us, 33.7 -> 32.2 us); below that it loses 0.3 us
+    const bool one_stage = nbuf == 1 || (nbuf == 0 && MODE == 0 && BM == 64 && BN == 64 && a.M >= 32768);
+    return one_stage ? launch_one_nb<BM, BN, BK, WM, WN, MODE, 1>(a, st) : launch_one_nb<BM, BN, BK, WM, WN, MODE, 2>(a, st);
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
