@@ -7,8 +7,12 @@ ResNet-v2-50 regressor -> mesh -> multi-grid warp -> feedback push.  Frames of a
 Inputs (the synthetic 720p clip) are resident in HBM before the timed region.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus N --steps K --warmup W        # N > 1 without a torchrun environment: this process starts N
+                                                       # fresh child ranks itself (before it touches the GPU), relays
+                                                       # rank 0's JSON line and exits non-zero if fewer than N came up
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W        # the driver's form: one rank per GPU over RCCL
+`n_gpus` in the line is the number of ranks the process group really has, never the flag.
 """
 import argparse
 import json
@@ -110,7 +114,9 @@ def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
     cfg = Config(height=H, width=W, batch_size=N)
     P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
     pg = dist.group.WORLD if dist is not None else None
-    tr = Trainer(P, N, H, W, cfg, device=dev, process_group=pg, world_size=world)
+    # STABNET_FORCE_COMM=1 (one-GPU box): main() built a ONE-rank RCCL group; the buckets still go through all_reduce on the
+    # communication stream, so `comm` is printed -- the launch / stream-join cost of the path, not a scaling number
+    tr = Trainer(P, N, H, W, cfg, device=dev, process_group=pg, world_size=world, force_comm=pg is not None)
     b = synthetic.make_train_batch(cfg, N, H, W, seed=1234 + rank)
     dev_b = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
     gates = {"use_theta_loss": 1, "use_temp_loss": 1, "use_black_loss": 1, "use_theta_only": 0}   # late-training values
@@ -120,7 +126,7 @@ def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    if world > 1:
+    if tr.comm:
         tr.comm_timing = []            # event pairs around every bucket's all-reduce on the communication stream
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -128,7 +134,7 @@ def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     comm = None
-    if world > 1:
+    if tr.comm:
         # all-reduce ms per step and the fraction of it hidden under backward.  exposed = time the
         # compute stream had to wait for the collective after its own last kernel (event on the compute stream before the
         # join vs the end of the last bucket on the communication stream).
@@ -140,7 +146,7 @@ def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
                 "overlap_fraction": (1.0 - exposed / ar_ms) if ar_ms > 0 else None,
                 "buckets_per_step": per_step, "bytes_per_step": sum(b for _, _, b in tr.comm_timing) // steps,
                 "order": "reverse layer order: FC+block4, block3, block2, block1+stem, BN gamma/beta",
-                "backend": dist.get_backend()}
+                "backend": dist.get_backend(), "ranks": dist.get_world_size()}
         tr.comm_timing = None
     if dist is not None:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -265,17 +271,81 @@ def cpu_baseline(P, clip, H, W, budget_s):
     return out
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def visible_gpus():
+    """Devices this process could use.  torch.cuda.device_count() does not initialise the GPU on this image, so the parent
+    of launch_ranks() stays GPU-free (a process that has touched the GPU must never be replaced or re-exec'd)."""
+    return torch.cuda.device_count()
+
+
+def launch_command(n, argv, env, ndev):
+    """The torch.distributed.run command line that starts `n` ranks of this script, or SystemExit when the box cannot hold
+    them: one rank per GPU over RCCL needs n devices (STABNET_DIST_BACKEND=gloo is the labelled rehearsal mode in which
+    ranks may share a card)."""
+    if env.get("STABNET_DIST_BACKEND", "nccl") == "nccl" and ndev < n:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; one rank per GPU over RCCL needs %d "
+                         "(rehearsal on fewer cards: STABNET_DIST_BACKEND=gloo)" % (n, ndev, n))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+            "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside a torchrun environment: start N FRESH child ranks (this process has made no
+    GPU call and makes none), relay their output, and return an exit code that is non-zero unless rank 0 printed a JSON
+    line whose n_gpus equals N."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = launch_command(args.gpus, argv, env, visible_gpus())
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    seen = None
+    for ln in proc.stdout:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            try:
+                seen = json.loads(ln)
+            except ValueError:
+                pass
+    rc = proc.wait()
+    if rc != 0:
+        print("bench.py: the rank launcher exited with %d" % rc, file=sys.stderr)
+        return rc
+    if seen is None or seen.get("n_gpus") != args.gpus:
+        print("bench.py: asked for %d ranks, the result line reports %s" % (args.gpus, None if seen is None else seen.get("n_gpus")),
+              file=sys.stderr)
+        return 3
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher environment has WORLD_SIZE=%d; they must agree "
+                         "(n_gpus is reported from the process group)" % (args.gpus, world))
     dist = None
     ndev = torch.cuda.device_count()
     dev_index = local_rank % max(ndev, 1)            # one rank per GPU; wraps only in the 1-GPU rehearsal below
-    if world > 1:
+    if world > 1 or os.environ.get("STABNET_FORCE_COMM") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(dev_index)
         # "nccl" = RCCL over xGMI.  STABNET_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks.
@@ -284,6 +354,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()                     # what the process group really has; this is what n_gpus reports
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     dev = torch.device("cuda", dev_index)

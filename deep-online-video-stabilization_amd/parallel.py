@@ -18,10 +18,12 @@ def env_world():
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(backend: str = None, device: torch.device = None):
+def init_process_group(backend: str = None, device: torch.device = None, single_rank_group: bool = False):
+    """single_rank_group: build the group even for world_size 1 (a one-rank RCCL communicator: how the collective code
+    path is run on a one-GPU box)."""
     import torch.distributed as dist
     rank, local_rank, world = env_world()
-    if world == 1:
+    if world == 1 and not single_rank_group:
         return None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")

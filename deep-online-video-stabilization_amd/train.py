@@ -44,7 +44,10 @@ def learning_rate(step: int, cfg: Config) -> float:
 
 class Trainer:
     def __init__(self, params, N: int, H: int, W: int, cfg: Config = v2_93, device="cuda:0", process_group=None,
-                 world_size: int = 1):
+                 world_size: int = 1, force_comm: bool = False):
+        """force_comm: run the communication path (buckets on the communication stream, wait_stream joins) even for a
+        one-rank group -- the sum over one rank is the identity, so the step must equal the no-group step bit for bit; that
+        is how the RCCL path is exercised on a one-GPU box (tests/test_rccl_gpu.py)."""
         self.cfg, self.N, self.H, self.W = cfg, N, H, W
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -78,7 +81,8 @@ class Trainer:
         self.global_step = 0
         self.pg = process_group
         self.world = world_size
-        self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
+        self.comm = world_size > 1 or (force_comm and process_group is not None)
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.comm else None
         self.last = None
         self.prof = None                                        # deploy.Profiler: per-launch HIP events (bench only)
         # gradient buckets in the order backward completes them (reverse layer order) + the BN gamma/beta sections
@@ -111,9 +115,9 @@ class Trainer:
             _lib.call("stabnet_towers_bwd_stage", self.plan.handle, ptr(self.params), ptr(d_theta1), ptr(d_theta2),
                       ptr(self.grads), ptr(self.ws[0]), ptr(self.ws[1]), self.ws_bytes, stage, stream_ptr(self.device), prof,
                       device=self.device)
-            if self.world > 1:
+            if self.comm:
                 self._allreduce_async(*self.buckets[stage])
-        if self.world > 1:
+        if self.comm:
             self._allreduce_async(*self.bn_bucket)
 
     def _allreduce_async(self, lo: int, hi: int):
@@ -190,7 +194,7 @@ class Trainer:
             mesh[k] = losses4
             d_thetas[k] = d_theta
         self._towers_bwd(d_thetas[0], d_thetas[1])
-        if self.world > 1:
+        if self.comm:
             if self.comm_timing is not None:          # bench: when did backward itself finish (vs the last bucket's end)?
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(torch.cuda.current_stream(self.device))
