@@ -436,10 +436,10 @@ def main():
         for row in table:                      # the HBM-bound kernel of the path: the fused map + gather warp
             if row["kernel"] == "warp_sample_kernel":
                 # sampler + feedback push in one launch: 20 HW (src, out, black, maps) + 12 HW (ring frame, ring mask, frame_fb)
-                roof_warp = {"bound": "hbm", "kernel": "warp_sample_kernel<4, 1>", "achieved": row["gbps"], "peak": PEAK_HBM_GBPS,
+                roof_warp = {"bound": "hbm", "kernel": "warp_sample_kernel<1>", "achieved": row["gbps"], "peak": PEAK_HBM_GBPS,
                              "unit": "GB/s", "frac": row["gbps"] / PEAK_HBM_GBPS, "avg_launch_us": row["avg_us"],
                              "algorithmic_bytes_per_launch": S * (32.0 * H * W + 776.0),
-                             "traffic": pmc_traffic("warp_sample_kernel<4, 1>", (H, W, S, args.refine) == (720, 1280, 1, 1))[0]}
+                             "traffic": pmc_traffic("warp_sample_kernel<1>", (H, W, S, args.refine) == (720, 1280, 1, 1))[0]}
         roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], (H, W, S, args.refine) == (720, 1280, 1, 1))
 
     bf16 = None

@@ -28,8 +28,10 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restri
 // block1 has a projection shortcut, so nothing reads the raw pooled tensor).
 __global__ __launch_bounds__(256) void max_pool_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H,
                                                        int W, int C, int Ho, int Wo, int k, int stride, int pt, int pl,
-                                                       const float* __restrict__ scale, const float* __restrict__ shift) {
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       unsigned* __restrict__ zero8) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (zero8 != nullptr && q < 8) zero8[q] = 0u;            // the fused head's phase counters (visible at the kernel boundary)
     const int c4n = C / 4;
     const long total = (long)N * Ho * Wo * c4n;
     if (q >= total) return;
@@ -260,9 +262,9 @@ int launch_pad_channels(const float* x, float* y, long npix, int C, int Cp, hipS
 }
 
 int launch_max_pool(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, int k, int stride, int pt,
-                    int pl, const float* scale, const float* shift, hipStream_t st) {
+                    int pl, const float* scale, const float* shift, hipStream_t st, unsigned* zero8) {
     SN_REQUIRE(C % 4 == 0, "max_pool: C %% 4 != 0");
-    max_pool_kernel<<<cdiv((long)N * Ho * Wo * (C / 4), 256), 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, k, stride, pt, pl, scale, shift);
+    max_pool_kernel<<<cdiv((long)N * Ho * Wo * (C / 4), 256), 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, k, stride, pt, pl, scale, shift, zero8);
     SN_LAUNCH_CHECK("max_pool_kernel");
     return STABNET_OK;
 }

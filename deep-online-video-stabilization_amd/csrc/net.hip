@@ -446,19 +446,29 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
         }
     }
     net->act_floats = ar.peak;
-    net->splitk_bytes = std::max(net->splitk_bytes, sizeof(float) * (size_t)N * gap_chunks(net->t_last.H * net->t_last.W) * net->t_last.C);
+    net->splitk_bytes = std::max(net->splitk_bytes, sizeof(float) * (size_t)N * std::max(8, gap_chunks(net->t_last.H * net->t_last.W)) * net->t_last.C);
     net->max_net = std::max({net->max_net, net->t_c1.size, net->t_pool.size});
     return net;
 }
 
+// What the online loop hangs behind the regressor's head: get_4_pts + get_Hs (+ the ring-head advance).  With the fused head
+// (head_chain.hip) they ride in its last phase; `done` tells the caller whether run_forward did them.
+struct MeshTail { int gh, gw; float lim; float* Hs; int* head_adv; int depth; bool done; };
+
 static int run_forward(const Net* net, const float* params, const float* fold, const float* x, float* theta,
-                       float* ws, hipStream_t st, Prof* prof = nullptr, bool skip_pad = false) {
+                       float* ws, hipStream_t st, Prof* prof = nullptr, bool skip_pad = false, MeshTail* mesh = nullptr) {
     float* splitk = ws + net->act_floats;
     const float* scale = fold;
     const float* shift = fold + net->G;
+    // the regressor's head (reduce_mean + FC chain [+ mesh]) as ONE launch where the shape and the device allow it
+    const bool chain = head_chain_supported(net->N, net->t_last.H * net->t_last.W, net->t_last.C, net->fc_dims,
+                                            mesh ? mesh->gh : 1, mesh ? mesh->gw : 1);
+    unsigned* sync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + net->act_floats * sizeof(float) + net->splitk_bytes);
+    if (mesh) mesh->done = false;
     for (const Step& s : net->steps) {
         int rc = STABNET_OK;
         if (s.kind == S_PAD && skip_pad) continue;
+        if (s.kind == S_FC && chain) continue;
         const bool rec = (s.kind != S_CONV) && prof != nullptr && prof->begin(st);
         switch (s.kind) {
             case S_PAD:
@@ -491,9 +501,31 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
             }
             case S_POOL:
                 rc = launch_max_pool(ws + s.in_off, ws + s.out_off, s.N, s.H, s.W, s.C, s.Ho, s.Wo, s.k, s.stride, s.pt,
-                                     s.pl, s.obn_off >= 0 ? scale + s.obn_off : nullptr, s.obn_off >= 0 ? shift + s.obn_off : nullptr, st);
+                                     s.pl, s.obn_off >= 0 ? scale + s.obn_off : nullptr, s.obn_off >= 0 ? shift + s.obn_off : nullptr, st,
+                                     chain ? sync : nullptr);                 // (zeroes the fused head's phase counters)
                 break;
             case S_GAP:
+                if (chain) {
+                    HeadChainArgs a{};
+                    a.x = ws + s.in_off; a.scale = scale + s.bn_off; a.shift = shift + s.bn_off;
+                    a.N = s.N; a.HW = s.H * s.W; a.C = s.C;
+                    for (int k = 0; k < 4; ++k) { a.w[k] = params + net->fc_w[k]; a.b[k] = params + net->fc_b[k]; }
+                    a.n_theta = net->n_theta;
+                    a.partial = splitk;                                       // partials live in the split-K scratch
+                    a.gap = ws + s.out_off;
+                    for (int k = 0; k < 3; ++k) a.fc[k] = ws + net->t_fc[k].off;
+                    a.theta = theta;
+                    a.sync = sync;
+                    if (mesh) {
+                        a.gh = mesh->gh; a.gw = mesh->gw; a.lim = mesh->lim; a.Hs = mesh->Hs; a.head_adv = mesh->head_adv;
+                        a.depth = mesh->depth;
+                        mesh->done = true;
+                    } else {
+                        a.gh = a.gw = 1;
+                    }
+                    rc = launch_head_chain(a, st);
+                    break;
+                }
                 rc = launch_gap_bn_relu(ws + s.in_off, scale + s.bn_off, shift + s.bn_off, s.N, s.H * s.W, s.C,
                                         ws + s.out_off, splitk, st);          // partials live in the split-K scratch
                 break;
@@ -509,6 +541,10 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
             if (s.kind == S_POOL) bytes = 4.0 * s.N * s.C * ((double)s.H * s.W + (double)s.Ho * s.Wo);
             if (s.kind == S_GAP) bytes = 4.0 * s.N * s.C * ((double)s.H * s.W + 1);
             if (s.kind == S_FC) bytes = 4.0 * ((double)s.K * s.Nout + (double)s.M * (s.K + s.Nout));
+            if (s.kind == S_GAP && chain) {                 // + the FC weights it streams
+                for (int k = 0; k < 4; ++k) bytes += 4.0 * net->fc_dims[k] * net->fc_dims[k + 1];
+                prof->end(st, PK_KERNEL_HEAD, 0.0, bytes);
+            } else
             prof->end(st, kmap[s.kind], s.kind == S_FC ? 2.0 * s.M * s.K * s.Nout : 0.0, bytes);
         }
         if (rc) return rc;
@@ -578,6 +614,7 @@ const char* stabnet_prof_kind_name(int kind) {
         case PK_KERNEL_GAP: return "gap_bn_relu_partial_kernel";
         case PK_KERNEL_FC: return "fc_kernel";
         case PK_KERNEL_MESH: return "mesh_homography_kernel";
+        case PK_KERNEL_HEAD: return "head_chain_kernel";
         case PK_KERNEL_WARP: return "warp_sample_kernel";
         case PK_KERNEL_ASSEMBLE: return "stack_assemble_bordered_kernel";
         case PK_KERNEL_PUSH: return "ring_push_kernel";
@@ -736,8 +773,8 @@ int stabnet_ring_init(float* frames_ring, float* masks_ring, const float* first_
 
 /* One iteration of the online loop for S = net.N independent streams (deploy_bundle.py:259-296,319-332):
  * stack assembly from the ring -> regressor -> get_4_pts + transformer -> frame = img - black -> push.
- * `head` (DEVICE int[2]) = {ring slot this frame's push writes, ticket counter (zero)}; the call advances head[0] to
- * (head+1) % depth on the device (last block of the sampler for refine = 1, a one-thread kernel otherwise), so the
+ * `head` (DEVICE int[2]) = {ring slot this frame's push writes, reserved}; the call advances head[0] to
+ * (head+1) % depth on the device (one thread of the mesh kernel for refine = 1, a one-thread kernel otherwise), so the
  * whole frame has fixed arguments and can be captured once into a hipGraph and replayed.
  * `lags` is a HOST array (read at enqueue time).  all_black (optional, int32 [S][H*W]) += round(black) once per refine
  * pass (deploy_bundle.py:291 sits inside the refine loop). */
@@ -773,7 +810,7 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
     const long hw = (long)net->H * net->W;
     const float* cur = cur_frame;
     float* x16 = ws + net->steps[0].out_off;
-    const bool fused_push = (refine == 1) && (net->W % 4 == 0);
+    const bool fused_push = (refine == 1);
     for (int j = 0; j < refine; ++j) {
         bool rec = prof && prof->begin(st);
         if (net->stem_rowrun)
@@ -782,16 +819,21 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
             rc = launch_stack_assemble(frames_ring, masks_ring, cur, net->N, depth, head, rl, hw, net->in_ch_act, x16, st);
         if (rec) prof->end(st, PK_KERNEL_ASSEMBLE, 0, 4.0 * net->N * hw * (net->in_ch + net->in_ch_act));
         if (rc) return rc;
-        rc = run_forward(net, params, fold, nullptr, theta, ws, st, prof, true);
+        // fused push: whoever computes the mesh also advances the ring head (nothing between the stack assembly and the
+        // sampler reads it): the fused head's last phase, or the mesh kernel
+        MeshTail mt{grid_h, grid_w, 1.0f / do_crop_rate, Hs, fused_push ? head : nullptr, depth, false};
+        rc = run_forward(net, params, fold, nullptr, theta, ws, st, prof, true, &mt);
         if (rc) return rc;
-        rec = prof && prof->begin(st);
-        rc = launch_mesh(theta, 1, net->N, grid_h, grid_w, 1.0f / do_crop_rate, nullptr, Hs, st);
-        if (rec) prof->end(st, PK_KERNEL_MESH, 0, 4.0 * net->N * (net->n_theta + grid_h * grid_w * 9));
-        if (rc) return rc;
+        if (!mt.done) {
+            rec = prof && prof->begin(st);
+            rc = launch_mesh(theta, 1, net->N, grid_h, grid_w, 1.0f / do_crop_rate, nullptr, Hs, st, nullptr, mt.head_adv, depth);
+            if (rec) prof->end(st, PK_KERNEL_MESH, 0, 4.0 * net->N * (net->n_theta + grid_h * grid_w * 9));
+            if (rc) return rc;
+        }
         // the frame being warped is the (possibly refined) current frame: channel 2*n_lags of the stack
         if (fused_push) {
-            // sampler + frame = img - black + push into the ring + all_black + head advance: ONE launch
-            WarpPush wp{frames_ring, masks_ring, frame_fb, all_black, head, head, head + 1, depth};
+            // sampler + frame = img - black + push into the ring + all_black: ONE launch (slot = advanced head - 1)
+            WarpPush wp{frames_ring, masks_ring, frame_fb, all_black, head, depth};
             rec = prof && prof->begin(st);
             rc = launch_sample_push(Hs, cur, net->N, net->H, net->W, grid_h, grid_w, out_img, black, x_map, y_map, wp, st);
             if (rec) prof->end(st, PK_KERNEL_WARP, 0, net->N * (32.0 * hw + 776.0) + (all_black ? 8.0 * net->N * hw : 0.0));

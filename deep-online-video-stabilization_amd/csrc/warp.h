@@ -2,17 +2,17 @@
 #pragma once
 #include "common.h"
 
+// head_adv (device int*, optional): the online loop's ring head, advanced to (head + 1) % depth by one thread of the mesh
+// kernel -- see launch_sample_push.
 int launch_mesh(const float* in, int is_theta, int N, int gh, int gw, float lim, float* pts2, float* Hs, hipStream_t st,
-                float* pts1 = nullptr);
-// feedback of the online loop fused behind the sampler (warp_sample_kernel<4, 1>)
+                float* pts1 = nullptr, int* head_adv = nullptr, int depth = 1);
+// feedback of the online loop fused behind the sampler (warp_sample_kernel<1>)
 struct WarpPush {
-    float* frames;        // ring [S][depth][H*W]: slot `*head` receives frame = img - black
-    float* masks;         // ring [S][depth][H*W]: slot `*head` receives black
+    float* frames;        // ring [S][depth][H*W]: slot (*head - 1) mod depth receives frame = img - black
+    float* masks;         // ring [S][depth][H*W]: the same slot receives black
     float* frame_out;     // [S][H*W]
     int* all_black;       // [S][H*W] int32 += round(black), or null
-    const int* head;      // device: slot of this frame's push
-    int* head_rw;         // same word, advanced by the last block
-    int* ticket;          // device counter, zero between launches
+    const int* head;      // device: the ring head, ALREADY advanced past this frame's slot (launch_mesh's head_adv)
     int depth;
 };
 int launch_sample_push(const float* Hs, const float* src, int N, int H, int W, int gh, int gw, float* out, float* black,

@@ -3,6 +3,7 @@
 //   mesh_homography_kernel : theta|pts2 -> pts2, Hs        one 64-lane wave per (sample, cell); the 8x8
 //                                                          system lives one element per lane (lane = 8*row+col)
 //   warp_sample_kernel     : Hs, frame -> x_map,y_map,black,out   fused map + divide + black test + 4-tap gather
+//                                                          (+ the online loop's feedback push, PUSH = 1)
 //   interp_kernel          : frame, x, y -> out            the same sampler with caller-supplied maps
 //
 // Arithmetic follows the reference op for op in float32, one rounding per TF op (this file is built with
@@ -11,11 +12,10 @@
 //   get_Hs      spatial_transformer3.py:179-198   _transform3 spatial_transformer3.py:218-301
 //   _interpolate spatial_transformer3.py:62-123   interpolate spatial_transformer.py:200-281
 #include "warp.h"
+#include "mesh_device.h"
 #include <climits>
 
 #define SN_MAX_CELLS 64
-
-__device__ __forceinline__ float wshfl(float v, int src) { return __shfl(v, src, 64); }
 
 // tf.cast(float->int32) on the reference's x86 host: cvttss2si, out of range / NaN -> INT_MIN.
 __device__ __forceinline__ int cvt_i32_x86(float f) {
@@ -25,108 +25,23 @@ __device__ __forceinline__ int cvt_i32_x86(float f) {
 // ---------------------------------------------------------------------------------------------------------
 // One wave per (n, cell).  in_is_theta: in = theta [N, (gh+1)(gw+1)*2] (vertex = regular grid + offset, clipped
 // to +-lim); else in = pts2 [N, gh+1, gw+1, 2] used as is.  Writes pts2 (optional) and Hs [N, gh*gw, 9].
-// LU with partial pivoting + two column-oriented triangular solves == Eigen PartialPivLU::inverse() for n=8.
+// The per-cell arithmetic lives in mesh_device.h (shared with the regressor's fused head).
 __global__ __launch_bounds__(256) void mesh_homography_kernel(const float* __restrict__ in, int in_is_theta, int N,
                                                               int gh, int gw, float lim, float* __restrict__ pts2_out,
-                                                              float* __restrict__ Hs_out, float* __restrict__ pts1_out) {
+                                                              float* __restrict__ Hs_out, float* __restrict__ pts1_out,
+                                                              int* __restrict__ head_adv, int depth) {
     const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
+    // online loop: nothing between the stack assembly and the sampler reads the ring head, and this kernel sits between them
+    // in the stream, so ONE thread advances it here; the sampler pushes to (*head - 1) mod depth (no last-block ticket).
+    if (head_adv != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *head_adv = (*head_adv + 1) % depth;
     const int cells = gh * gw;
     if (wave >= N * cells) return;                       // wave-uniform exit
     const int n = wave / cells, cell = wave % cells;
-    const int ci = cell / gw, cj = cell % gw;
-    const double hh = 2.0 / gh, ww = 2.0 / gw;
     const int nv = (gh + 1) * (gw + 1);
-
-    // source corners (regular cell) and target corners (mesh vertices): order TL, TR, BL, BR
-    float sx[4], sy[4], tu[4], tv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int vi = ci + (q >> 1), vj = cj + (q & 1);
-        const double bx = cj * ww - 1.0, by = ci * hh - 1.0;          // spatial_transformer3.py:187-189
-        sx[q] = (float)((q & 1) ? bx + ww : bx);
-        sy[q] = (float)((q >> 1) ? by + hh : by);
-        const int v = vi * (gw + 1) + vj;
-        float px = in[((size_t)n * nv + v) * 2 + 0];
-        float py = in[((size_t)n * nv + v) * 2 + 1];
-        if (in_is_theta) {                                             // s_net_bundle_nobm.py:44-58
-            px = (float)(vj * ww - 1.0) + px;
-            py = (float)(vi * hh - 1.0) + py;
-            px = fminf(fmaxf(px, -lim), lim);
-            py = fminf(fmaxf(py, -lim), lim);
-        }
-        tu[q] = px;
-        tv[q] = py;
-        if (pts2_out != nullptr && lane == q) {
-            // each vertex is written by every cell that owns it with the same value
-            pts2_out[((size_t)n * nv + v) * 2 + 0] = px;
-            pts2_out[((size_t)n * nv + v) * 2 + 1] = py;
-        }
-    }
-    if (pts1_out != nullptr && lane < 8)                 // [x_TL,x_TR,x_BL,x_BR,y_TL,y_TR,y_BL,y_BR], s_net_bundle_nobm.py:65-66
-        pts1_out[((size_t)n * cells + cell) * 8 + lane] = (lane < 4) ? tu[lane & 3] : tv[lane & 3];
-
-    const int r = lane >> 3, c = lane & 7;
-    const int q = r & 3;
-    const float tq = (r < 4) ? tu[q] : tv[q];
-    float a;
-    {   // A[r][c], spatial_transformer3.py:160-167
-        const int cc = (r < 4) ? c : c - 3;             // u-rows use cols 0..2, v-rows cols 3..5
-        float val = 0.0f;
-        if (c < 6) {
-            if (cc == 0) val = sx[q];
-            else if (cc == 1) val = sy[q];
-            else if (cc == 2) val = 1.0f;
-            else val = 0.0f;
-            if ((r < 4 && c >= 3) || (r >= 4 && c < 3)) val = 0.0f;
-        } else if (c == 6) {
-            val = (-sx[q]) * tq;
-        } else {
-            val = (-sy[q]) * tq;
-        }
-        a = val + ((r == c) ? 1e-4f : 0.0f);            // A + eye(8)*1e-4, :145
-    }
-    float x = (r == c) ? 1.0f : 0.0f;                   // right-hand side: identity, row-swapped with A (P*I)
-
-    for (int k = 0; k < 8; ++k) {
-        float best = -1.0f;
-        int piv = k;
-        for (int rr = k; rr < 8; ++rr) {                // first max |A[rr][k]|
-            const float v = fabsf(wshfl(a, rr * 8 + k));
-            if (v > best) { best = v; piv = rr; }
-        }
-        const int src = (r == k) ? piv * 8 + c : ((r == piv) ? k * 8 + c : lane);
-        a = wshfl(a, src);
-        x = wshfl(x, src);
-        const float pivot = wshfl(a, k * 8 + k);
-        if (r > k && c == k) a = a / pivot;
-        const float l = wshfl(a, r * 8 + k);
-        const float u = wshfl(a, k * 8 + c);
-        if (r > k && c > k) a = a - l * u;
-    }
-    for (int i = 0; i < 8; ++i) {                       // unit-lower solve
-        const float b = wshfl(x, i * 8 + c);
-        const float l = wshfl(a, r * 8 + i);
-        if (r > i) x = x - b * l;
-    }
-    for (int i = 7; i >= 0; --i) {                      // upper solve, reciprocal-diagonal form
-        const float d = wshfl(a, i * 8 + i);
-        const float inv = 1.0f / d;
-        if (r == i) x = x * inv;
-        const float b = wshfl(x, i * 8 + c);
-        const float u = wshfl(a, r * 8 + i);
-        if (r < i) x = x - b * u;
-    }
-    float acc = 0.0f;                                   // h = inv(A) @ b, k-sequential
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float xk = wshfl(x, r * 8 + k);
-        const float bk = (k < 4) ? tu[k & 3] : tv[k & 3];
-        acc = acc + xk * bk;
-    }
-    float* Hout = Hs_out + ((size_t)n * cells + cell) * 9;
-    if (c == 0) Hout[r] = acc;
-    if (lane == 63) Hout[8] = 1.0f;
+    sn_mesh_cell(in + (size_t)n * nv * 2, in_is_theta, gh, gw, lim, cell, lane,
+                 pts2_out ? pts2_out + (size_t)n * nv * 2 : nullptr, Hs_out + (size_t)n * cells * 9,
+                 pts1_out ? pts1_out + (size_t)n * cells * 8 : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -165,105 +80,121 @@ __device__ __forceinline__ float sample4(const float* __restrict__ img, const Sa
     return ((t.wa * Ia + t.wb * Ib) + t.wc * Ic) + t.wd * Id;          // tf.add_n order, :122
 }
 
-// Tile = 4 rows x 256 columns per 256-thread block; thread = 4 consecutive pixels of one row.
-// grid = (ceil(W/256), ceil(H/4), N).
-// PUSH = 1 (online loop, C == 1, W % 4 == 0): the feedback of deploy_bundle.py:291-295,319-323 rides on the same pass --
-//   frame = img + black * (-1) -> frames_ring[head], black -> masks_ring[head], frame -> frame_out, all_black += round(black)
-//   -- and the LAST block to finish (ticket counter) advances the device-side ring head, so the frame needs no push /
-//   advance launches.  Every block reads `head` before it takes its ticket, so the advance cannot overtake a reader.
-template <int VEC, int PUSH>
+// Tiling (measured: tools/warp_probe.hip, profiles/r03_warp_probe.txt).  One wave = SN_WARP_PX * 64 CONSECUTIVE pixels of one
+// row, lane-strided (pixel e of lane l = x0 + 64 e + l): every gather and every store instruction of a wave touches 64
+// consecutive pixels (256 contiguous bytes), W needs no alignment.  A block = 4 consecutive wave segments; grid.y = sample.
+// The whole segment usually lies in ONE cell column, so the cell's 9 homography entries are wave-uniform scalar loads (no LDS
+// staging, no barrier); a segment that straddles a cell edge reads them per lane.  All 4 * PX taps of a thread are issued
+// before the first blend.  x_map / y_map / black / out are written with non-temporal stores (nothing on the GPU re-reads them
+// soon), the feedback planes with plain stores (the next frame's stack assembly reads them).
+// 720p sampler + push: 16.8 us (4 pixels per thread + LDS staging + last-block ticket) -> 8.0 us; 7.3 us of the 16.8 were the
+// ticket (one device-scope atomic per block on one address).
+// PUSH = 1 (online loop, C == 1): the feedback of deploy_bundle.py:291-295,319-323 rides on the same pass --
+//   frame = img + black * (-1) -> frames_ring[slot], black -> masks_ring[slot], frame -> frame_out, all_black += round(black)
+//   -- with slot = (*head - 1) mod depth: the ring head has ALREADY been advanced by the mesh kernel that precedes this
+//   launch in the stream (launch_mesh's head_adv; the kernel boundary orders it), so no block has to take a ticket.
+#define SN_WARP_PX 2
+template <int PUSH>
 __global__ __launch_bounds__(256) void warp_sample_kernel(const float* __restrict__ Hs, const float* __restrict__ src,
                                                           int H, int W, int C, int gh, int gw,
                                                           float* __restrict__ out, float* __restrict__ black,
                                                           float* __restrict__ x_map, float* __restrict__ y_map,
                                                           const WarpPush push) {
-    __shared__ float sH[SN_MAX_CELLS * 9];
-    const int n = blockIdx.z;
+    constexpr int PX = SN_WARP_PX;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = blockIdx.y;
+    const int segs = (W + 64 * PX - 1) / (64 * PX);           // wave segments per row
+    const int wseg = blockIdx.x * 4 + wv;
+    const int y = wseg / segs;
+    if (y >= H) return;                                        // wave-uniform
+    const int x0 = (wseg - y * segs) * (64 * PX);
+    int slot = 0;
+    if (PUSH) {
+        slot = *push.head - 1;
+        if (slot < 0) slot += push.depth;
+    }
     const int cells = gh * gw;
-    for (int i = threadIdx.x; i < cells * 9; i += 256) sH[i] = Hs[(size_t)n * cells * 9 + i];
-    int head = 0;
-    if (PUSH) head = *push.head;
-    __syncthreads();
+    const int chh = H / gh, cww = W / gw;                      // floor, :227-228
+    const int ci = min(y / chh, gh - 1);
+    const float stepx = (W > 1) ? 2.0f / (float)(W - 1) : 0.0f;           // LinSpace: start + step*i
+    const float stepy = (H > 1) ? 2.0f / (float)(H - 1) : 0.0f;
+    const float gy = -1.0f + stepy * (float)y;
+    const float* img = src + (size_t)n * H * W * C;
+    const float* Hn = Hs + (size_t)n * cells * 9;
+    const size_t rowoff = ((size_t)n * H + y) * W;
 
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int y = blockIdx.y * 4 + wv;
-    const int xb = blockIdx.x * 256 + lane * 4;
-    if (y < H && xb < W) {
-        const int chh = H / gh, cww = W / gw;               // floor, :227-228
-        const int ci = min(y / chh, gh - 1);
-        const float stepx = (W > 1) ? 2.0f / (float)(W - 1) : 0.0f;       // LinSpace: start + step*i
-        const float stepy = (H > 1) ? 2.0f / (float)(H - 1) : 0.0f;
-        const float gy = -1.0f + stepy * (float)y;
-        const float* img = src + (size_t)n * H * W * C;
-        const size_t rowoff = ((size_t)n * H + y) * W;
-
-        float xm[4], ym[4], bl[4], o[4];
+    float xm[PX], ym[PX], bl[PX];
+    auto map_px = [&](const float* h, int e) {
+        const int xx = min(x0 + e * 64 + lane, W - 1);
+        const float gx = -1.0f + stepx * (float)xx;
+        const float tx = (h[0] * gx + h[1] * gy) + h[2];
+        const float ty = (h[3] * gx + h[4] * gy) + h[5];
+        float tz = (h[6] * gx + h[7] * gy) + h[8];
+        const float sgn = ((tz >= 0.0f) ? 1.0f : 0.0f) * 2.0f - 1.0f;  // :257
+        tz = tz + sgn * 1e-8f;                                          // :258
+        xm[e] = tx / tz;
+        ym[e] = ty / tz;
+        bl[e] = ((-1.0f > xm[e]) || (xm[e] > 1.0f) || (-1.0f > ym[e]) || (ym[e] > 1.0f)) ? 1.0f : 0.0f;
+    };
+    const int cj0 = min(x0 / cww, gw - 1), cj1 = min(min(x0 + 64 * PX - 1, W - 1) / cww, gw - 1);
+    if (cj0 == cj1) {                                          // wave-uniform: the segment lies in one cell
+        const float* hp = Hn + (ci * gw + cj0) * 9;
+        float h[9];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int xx = min(xb + e, W - 1);
-            const int cj = min(xx / cww, gw - 1);
-            const float* h = sH + (ci * gw + cj) * 9;
-            const float gx = -1.0f + stepx * (float)xx;
-            const float tx = (h[0] * gx + h[1] * gy) + h[2];
-            const float ty = (h[3] * gx + h[4] * gy) + h[5];
-            float tz = (h[6] * gx + h[7] * gy) + h[8];
-            const float sgn = ((tz >= 0.0f) ? 1.0f : 0.0f) * 2.0f - 1.0f;  // :257
-            tz = tz + sgn * 1e-8f;                                          // :258
-            xm[e] = tx / tz;
-            ym[e] = ty / tz;
-            bl[e] = ((-1.0f > xm[e]) || (xm[e] > 1.0f) || (-1.0f > ym[e]) || (ym[e] > 1.0f)) ? 1.0f : 0.0f;
-        }
-        if (C == 1) {
+        for (int i = 0; i < 9; ++i) h[i] = hp[i];              // uniform address -> scalar loads
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const SampleTaps t = make_taps(xm[e], ym[e], H, W);
-                o[e] = sample4(img, t, 1, 0);
-            }
-        }
-        if (VEC == 4 && xb + 3 < W) {
-            *reinterpret_cast<float4*>(x_map + rowoff + xb) = make_float4(xm[0], xm[1], xm[2], xm[3]);
-            *reinterpret_cast<float4*>(y_map + rowoff + xb) = make_float4(ym[0], ym[1], ym[2], ym[3]);
-            *reinterpret_cast<float4*>(black + rowoff + xb) = make_float4(bl[0], bl[1], bl[2], bl[3]);
-            if (C == 1) *reinterpret_cast<float4*>(out + rowoff + xb) = make_float4(o[0], o[1], o[2], o[3]);
-            if (PUSH) {
-                const size_t hw = (size_t)H * W, pix = (size_t)y * W + xb;
-                const float4 f = make_float4(o[0] + bl[0] * -1.0f, o[1] + bl[1] * -1.0f, o[2] + bl[2] * -1.0f,
-                                             o[3] + bl[3] * -1.0f);                                    // :293
-                const size_t slot = ((size_t)n * push.depth + head) * hw + pix;
-                *reinterpret_cast<float4*>(push.frames + slot) = f;                                    // :322
-                *reinterpret_cast<float4*>(push.masks + slot) = make_float4(bl[0], bl[1], bl[2], bl[3]);   // :323
-                *reinterpret_cast<float4*>(push.frame_out + (size_t)n * hw + pix) = f;
-                if (push.all_black != nullptr) {                                                       // :291
-                    int4* ab = reinterpret_cast<int4*>(push.all_black + (size_t)n * hw + pix);
-                    int4 v = *ab;
-                    v.x += (int)bl[0]; v.y += (int)bl[1]; v.z += (int)bl[2]; v.w += (int)bl[3];
-                    *ab = v;
-                }
-            }
-        } else {
-            for (int e = 0; e < 4 && xb + e < W; ++e) {
-                x_map[rowoff + xb + e] = xm[e];
-                y_map[rowoff + xb + e] = ym[e];
-                black[rowoff + xb + e] = bl[e];
-                if (C == 1) out[rowoff + xb + e] = o[e];
-            }
-        }
-        if (C != 1) {
-            for (int e = 0; e < 4 && xb + e < W; ++e) {
-                const SampleTaps t = make_taps(xm[e], ym[e], H, W);
-                for (int ch = 0; ch < C; ++ch) out[(rowoff + xb + e) * C + ch] = sample4(img, t, C, ch);
-            }
+        for (int e = 0; e < PX; ++e) map_px(h, e);
+    } else {
+#pragma unroll
+        for (int e = 0; e < PX; ++e) {
+            const int cj = min(min(x0 + e * 64 + lane, W - 1) / cww, gw - 1);
+            const float* hp = Hn + (ci * gw + cj) * 9;
+            float h[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) h[i] = hp[i];
+            map_px(h, e);
         }
     }
-    if (PUSH) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-            const unsigned old = atomicAdd(reinterpret_cast<unsigned*>(push.ticket), 1u);
-            if (old == total - 1) {                       // every block has read `head` (before its own ticket)
-                *push.ticket = 0;
-                *push.head_rw = (head + 1) % push.depth;
+    if (C == 1) {
+        SampleTaps t[PX];
+        float Ia[PX], Ib[PX], Ic[PX], Id[PX];
+#pragma unroll
+        for (int e = 0; e < PX; ++e) {
+            t[e] = make_taps(xm[e], ym[e], H, W);
+            Ia[e] = img[t[e].ia]; Ib[e] = img[t[e].ib]; Ic[e] = img[t[e].ic]; Id[e] = img[t[e].id];
+        }
+        const size_t hw = (size_t)H * W;
+#pragma unroll
+        for (int e = 0; e < PX; ++e) {
+            const int xx = x0 + e * 64 + lane;
+            if (xx >= W) continue;
+            const float o = ((t[e].wa * Ia[e] + t[e].wb * Ib[e]) + t[e].wc * Ic[e]) + t[e].wd * Id[e];   // tf.add_n order, :122
+            const size_t pix = rowoff + xx;
+            __builtin_nontemporal_store(xm[e], x_map + pix);
+            __builtin_nontemporal_store(ym[e], y_map + pix);
+            __builtin_nontemporal_store(bl[e], black + pix);
+            __builtin_nontemporal_store(o, out + pix);
+            if (PUSH) {
+                const float f = o + bl[e] * -1.0f;                                                     // :293
+                const size_t ipix = (size_t)y * W + xx;
+                const size_t rp = ((size_t)n * push.depth + slot) * hw + ipix;
+                push.frames[rp] = f;                                                                   // :322
+                push.masks[rp] = bl[e];                                                                // :323
+                push.frame_out[(size_t)n * hw + ipix] = f;
+                if (push.all_black != nullptr) push.all_black[(size_t)n * hw + ipix] += (int)bl[e];    // :291
             }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < PX; ++e) {
+            const int xx = x0 + e * 64 + lane;
+            if (xx >= W) continue;
+            const size_t pix = rowoff + xx;
+            x_map[pix] = xm[e];
+            y_map[pix] = ym[e];
+            black[pix] = bl[e];
+            const SampleTaps t = make_taps(xm[e], ym[e], H, W);
+            for (int ch = 0; ch < C; ++ch) out[pix * C + ch] = sample4(img, t, C, ch);
         }
     }
 }
@@ -272,27 +203,31 @@ __global__ __launch_bounds__(256) void warp_sample_kernel(const float* __restric
 __global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ im, const float* __restrict__ xs,
                                                      const float* __restrict__ ys, int H, int W, int C,
                                                      float* __restrict__ out) {
-    const int n = blockIdx.z;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int y = blockIdx.y * 4 + wv;
-    const int xb = blockIdx.x * 256 + lane * 4;
-    if (y >= H || xb >= W) return;
+    constexpr int PX = SN_WARP_PX;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = blockIdx.y;
+    const int segs = (W + 64 * PX - 1) / (64 * PX);
+    const int wseg = blockIdx.x * 4 + wv;
+    const int y = wseg / segs;
+    if (y >= H) return;
+    const int x0 = (wseg - y * segs) * (64 * PX);
     const float* img = im + (size_t)n * H * W * C;
     const size_t rowoff = ((size_t)n * H + y) * W;
-    if (C == 1 && (W & 3) == 0) {
-        const float4 xv = *reinterpret_cast<const float4*>(xs + rowoff + xb);
-        const float4 yv = *reinterpret_cast<const float4*>(ys + rowoff + xb);
-        float4 o;
-        o.x = sample4(img, make_taps(xv.x, yv.x, H, W), 1, 0);
-        o.y = sample4(img, make_taps(xv.y, yv.y, H, W), 1, 0);
-        o.z = sample4(img, make_taps(xv.z, yv.z, H, W), 1, 0);
-        o.w = sample4(img, make_taps(xv.w, yv.w, H, W), 1, 0);
-        *reinterpret_cast<float4*>(out + rowoff + xb) = o;
-    } else {
-        for (int e = 0; e < 4 && xb + e < W; ++e) {
-            const SampleTaps t = make_taps(xs[rowoff + xb + e], ys[rowoff + xb + e], H, W);
-            for (int ch = 0; ch < C; ++ch) out[(rowoff + xb + e) * C + ch] = sample4(img, t, C, ch);
-        }
+    SampleTaps t[PX];
+    float Ia[PX], Ib[PX], Ic[PX], Id[PX];
+#pragma unroll
+    for (int e = 0; e < PX; ++e) {
+        const size_t pix = rowoff + min(x0 + e * 64 + lane, W - 1);
+        t[e] = make_taps(xs[pix], ys[pix], H, W);
+        if (C == 1) { Ia[e] = img[t[e].ia]; Ib[e] = img[t[e].ib]; Ic[e] = img[t[e].ic]; Id[e] = img[t[e].id]; }
+    }
+#pragma unroll
+    for (int e = 0; e < PX; ++e) {
+        const int xx = x0 + e * 64 + lane;
+        if (xx >= W) continue;
+        const size_t pix = rowoff + xx;
+        if (C == 1) out[pix] = ((t[e].wa * Ia[e] + t[e].wb * Ib[e]) + t[e].wc * Ic[e]) + t[e].wd * Id[e];
+        else for (int ch = 0; ch < C; ++ch) out[pix * C + ch] = sample4(img, t[e], C, ch);
     }
 }
 
@@ -308,32 +243,32 @@ int check_warp_args(int N, int H, int W, int C, int gh, int gw) {
 }
 
 int launch_mesh(const float* in, int is_theta, int N, int gh, int gw, float lim, float* pts2, float* Hs,
-                       hipStream_t st, float* pts1) {
+                       hipStream_t st, float* pts1, int* head_adv, int depth) {
     const long waves = (long)N * gh * gw;
-    mesh_homography_kernel<<<cdiv(waves * 64, 256), 256, 0, st>>>(in, is_theta, N, gh, gw, lim, pts2, Hs, pts1);
+    mesh_homography_kernel<<<cdiv(waves * 64, 256), 256, 0, st>>>(in, is_theta, N, gh, gw, lim, pts2, Hs, pts1, head_adv, depth);
     SN_LAUNCH_CHECK("mesh_homography_kernel");
     return STABNET_OK;
 }
 
+static dim3 sample_grid(int N, int H, int W) {
+    const long segs = cdiv(W, 64 * SN_WARP_PX);
+    return dim3((unsigned)cdiv(segs * H, 4), (unsigned)N, 1);
+}
+
 int launch_sample(const float* Hs, const float* src, int N, int H, int W, int C, int gh, int gw, float* out,
                          float* black, float* x_map, float* y_map, hipStream_t st) {
-    dim3 grid(cdiv(W, 256), cdiv(H, 4), N);
     const WarpPush none{};
-    if ((W & 3) == 0)
-        warp_sample_kernel<4, 0><<<grid, 256, 0, st>>>(Hs, src, H, W, C, gh, gw, out, black, x_map, y_map, none);
-    else
-        warp_sample_kernel<1, 0><<<grid, 256, 0, st>>>(Hs, src, H, W, C, gh, gw, out, black, x_map, y_map, none);
+    warp_sample_kernel<0><<<sample_grid(N, H, W), 256, 0, st>>>(Hs, src, H, W, C, gh, gw, out, black, x_map, y_map, none);
     SN_LAUNCH_CHECK("warp_sample_kernel");
     return STABNET_OK;
 }
 
-// The online loop's last pass: sample + feedback push + ring-head advance in one launch (C = 1, W % 4 == 0).
+// The online loop's last pass: sample + feedback push in one launch (C = 1).  *push.head must already be the ADVANCED head
+// (launch_mesh(..., head_adv) earlier in the same stream): the push goes to slot (*head - 1) mod depth.
 int launch_sample_push(const float* Hs, const float* src, int N, int H, int W, int gh, int gw, float* out, float* black,
                        float* x_map, float* y_map, const WarpPush& push, hipStream_t st) {
-    SN_REQUIRE((W & 3) == 0 && push.frames && push.masks && push.frame_out && push.head && push.head_rw && push.ticket &&
-                   push.depth > 0, "sample_push: bad arguments");
-    dim3 grid(cdiv(W, 256), cdiv(H, 4), N);
-    warp_sample_kernel<4, 1><<<grid, 256, 0, st>>>(Hs, src, H, W, 1, gh, gw, out, black, x_map, y_map, push);
+    SN_REQUIRE(push.frames && push.masks && push.frame_out && push.head && push.depth > 0, "sample_push: bad arguments");
+    warp_sample_kernel<1><<<sample_grid(N, H, W), 256, 0, st>>>(Hs, src, H, W, 1, gh, gw, out, black, x_map, y_map, push);
     SN_LAUNCH_CHECK("warp_sample_kernel");
     return STABNET_OK;
 }
@@ -383,8 +318,7 @@ int stabnet_interp_fwd(const float* im, const float* x, const float* y, int N, i
     SN_REQUIRE(im && x && y && out, "interp_fwd: null pointer");
     SN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && N <= 65535, "interp_fwd: bad shape");
     SN_REQUIRE((long)N * H * W * C < (1L << 31), "interp_fwd: tensor too large for int32 gather indices");
-    dim3 grid(cdiv(W, 256), cdiv(H, 4), N);
-    interp_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(im, x, y, H, W, C, out);
+    interp_kernel<<<sample_grid(N, H, W), 256, 0, (hipStream_t)stream>>>(im, x, y, H, W, C, out);
     SN_LAUNCH_CHECK("interp_kernel");
     return STABNET_OK;
 }

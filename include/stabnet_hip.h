@@ -136,9 +136,10 @@ int stabnet_ring_init(float* frames_ring, float* masks_ring, const float* first_
  * the feedback after it:  13-channel stack from the ring at the dilated `lags` (HOST int array, e.g. 1,2,4,8,16,32;
  * channel order masks, frames, current) -> regressor -> get_4_pts -> transformer -> frame = img - black ->
  * frames_ring[head] = frame, masks_ring[head] = black.  refine > 1 repeats the network on the refined frame
- * (:284-295).  `head` is a DEVICE int[2] = {ring slot of this frame's push, ticket counter (zero it once)}; the call
- * advances head[0] to (head+1) % depth on the device (by the last block of the sampler when refine = 1 -- sampler,
- * feedback push and advance are one launch -- else by a one-thread kernel), so every argument is fixed across frames
+ * (:284-295).  `head` is a DEVICE int[2] = {ring slot of this frame's push, reserved (zero)}; the call
+ * advances head[0] to (head+1) % depth on the device (refine = 1: by one thread of the mesh kernel, which sits between
+ * the last reader of the head -- the stack assembly -- and the sampler, whose fused feedback push then writes slot
+ * head - 1; else by a one-thread kernel at the end), so every argument is fixed across frames
  * and the call can be captured into a hipGraph once and replayed (copy the new frame into the fixed `cur_frame` buffer
  * before each replay).  all_black (optional, may be NULL): int32 [S,H,W] += round(black) once per refine pass
  * (deploy_bundle.py:291, inside the refine loop) -- the input of stabnet_crop_search.
