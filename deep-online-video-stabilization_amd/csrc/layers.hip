@@ -28,10 +28,8 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restri
 // block1 has a projection shortcut, so nothing reads the raw pooled tensor).
 __global__ __launch_bounds__(256) void max_pool_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H,
                                                        int W, int C, int Ho, int Wo, int k, int stride, int pt, int pl,
-                                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       unsigned* __restrict__ zero8) {
+                                                       const float* __restrict__ scale, const float* __restrict__ shift) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    if (zero8 != nullptr && q < 8) zero8[q] = 0u;            // the fused head's phase counters (visible at the kernel boundary)
     const int c4n = C / 4;
     const long total = (long)N * Ho * Wo * c4n;
     if (q >= total) return;
@@ -86,10 +84,21 @@ __global__ __launch_bounds__(256) void gap_bn_relu_partial_kernel(const float* _
     if (c < C) {
         const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
         const float* p = x + (size_t)n * HW * C + c;
-        for (int i = r0 + rl; i < r1; i += 16) {
-            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)i * C);
-            s.x += fmaxf(v.x * sc.x + sh.x, 0.f); s.y += fmaxf(v.y * sc.y + sh.y, 0.f);
-            s.z += fmaxf(v.z * sc.z + sh.z, 0.f); s.w += fmaxf(v.w * sc.w + sh.w, 0.f);
+        for (int ib = r0 + rl; ib < r1; ib += 128) {       // eight rows per trip, their loads issued together (same row order)
+            float4 xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = ib + 16 * j;
+                xv[j] = (i < r1) ? *reinterpret_cast<const float4*>(p + (size_t)i * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (ib + 16 * j < r1) {
+                    const float4 v = xv[j];
+                    s.x += fmaxf(__builtin_fmaf(v.x, sc.x, sh.x), 0.f); s.y += fmaxf(__builtin_fmaf(v.y, sc.y, sh.y), 0.f);
+                    s.z += fmaxf(__builtin_fmaf(v.z, sc.z, sh.z), 0.f); s.w += fmaxf(__builtin_fmaf(v.w, sc.w, sh.w), 0.f);
+                }
+            }
         }
     }
     part[rl][q] = s;
@@ -262,9 +271,9 @@ int launch_pad_channels(const float* x, float* y, long npix, int C, int Cp, hipS
 }
 
 int launch_max_pool(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, int k, int stride, int pt,
-                    int pl, const float* scale, const float* shift, hipStream_t st, unsigned* zero8) {
+                    int pl, const float* scale, const float* shift, hipStream_t st) {
     SN_REQUIRE(C % 4 == 0, "max_pool: C %% 4 != 0");
-    max_pool_kernel<<<cdiv((long)N * Ho * Wo * (C / 4), 256), 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, k, stride, pt, pl, scale, shift, zero8);
+    max_pool_kernel<<<cdiv((long)N * Ho * Wo * (C / 4), 256), 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, k, stride, pt, pl, scale, shift);
     SN_LAUNCH_CHECK("max_pool_kernel");
     return STABNET_OK;
 }
@@ -287,6 +296,16 @@ int launch_gap_bn_relu(const float* x, const float* scale, const float* shift, i
     SN_LAUNCH_CHECK("gap_bn_relu_partial_kernel");
     gap_finalize_kernel<<<dim3(cdiv(C, 256), N), 256, 0, st>>>(partial, chunks, HW, C, out);
     SN_LAUNCH_CHECK("gap_finalize_kernel");
+    return STABNET_OK;
+}
+
+// partial[n][chunk][c] = sum over the chunk's rows of relu(bn(x)) (the first launch of launch_gap_bn_relu with a caller-chosen
+// chunk count: the inference head sums the chunks inside fc_1's input staging, head.hip)
+int launch_gap_partial(const float* x, const float* scale, const float* shift, int N, int HW, int C, int chunks, float* partial,
+                       hipStream_t st) {
+    SN_REQUIRE(N <= 65535 && C % 4 == 0 && chunks >= 1, "gap: bad shape");
+    gap_bn_relu_partial_kernel<<<dim3(cdiv(C, 64), chunks, N), 256, 0, st>>>(x, scale, shift, HW, C, cdiv(HW, chunks), partial);
+    SN_LAUNCH_CHECK("gap_bn_relu_partial_kernel");
     return STABNET_OK;
 }
 

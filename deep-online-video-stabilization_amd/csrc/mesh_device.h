@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 __device__ __forceinline__ float sn_wshfl(float v, int src) { return __shfl(v, src, 64); }
+// a[q] for a per-lane q without private-memory indexing (a dynamically indexed register array lands in scratch)
+__device__ __forceinline__ float sn_sel4(const float (&a)[4], int q) { return q == 0 ? a[0] : (q == 1 ? a[1] : (q == 2 ? a[2] : a[3])); }
 
 // in_n: this sample's theta [(gh+1)(gw+1)*2] (in_is_theta: vertex = regular grid + offset, clipped to +-lim) or its
 // pts2 [gh+1, gw+1, 2] used as is; may point into LDS.  Writes pts2_n (optional), Hs_n [gh*gw, 9], pts1_n (optional).
@@ -40,25 +42,26 @@ __device__ __forceinline__ void sn_mesh_cell(const float* in_n, int in_is_theta,
         }
     }
     if (pts1_n != nullptr && lane < 8)                   // [x_TL,x_TR,x_BL,x_BR,y_TL,y_TR,y_BL,y_BR], s_net_bundle_nobm.py:65-66
-        pts1_n[cell * 8 + lane] = (lane < 4) ? tu[lane & 3] : tv[lane & 3];
+        pts1_n[cell * 8 + lane] = (lane < 4) ? sn_sel4(tu, lane & 3) : sn_sel4(tv, lane & 3);
 
     const int r = lane >> 3, c = lane & 7;
     const int q = r & 3;
-    const float tq = (r < 4) ? tu[q] : tv[q];
+    const float tq = (r < 4) ? sn_sel4(tu, q) : sn_sel4(tv, q);
+    const float sxq = sn_sel4(sx, q), syq = sn_sel4(sy, q);
     float a;
     {   // A[r][c], spatial_transformer3.py:160-167
         const int cc = (r < 4) ? c : c - 3;             // u-rows use cols 0..2, v-rows cols 3..5
         float val = 0.0f;
         if (c < 6) {
-            if (cc == 0) val = sx[q];
-            else if (cc == 1) val = sy[q];
+            if (cc == 0) val = sxq;
+            else if (cc == 1) val = syq;
             else if (cc == 2) val = 1.0f;
             else val = 0.0f;
             if ((r < 4 && c >= 3) || (r >= 4 && c < 3)) val = 0.0f;
         } else if (c == 6) {
-            val = (-sx[q]) * tq;
+            val = (-sxq) * tq;
         } else {
-            val = (-sy[q]) * tq;
+            val = (-syq) * tq;
         }
         a = val + ((r == c) ? 1e-4f : 0.0f);            // A + eye(8)*1e-4, :145
     }

@@ -379,6 +379,7 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
     add_tap(*net, "global_pool", g);
     const int dims[4] = {cur.C, 2048, 1024, 512};
     TensorRef f = g;
+    // (the head's few KB of vectors stay allocated together; nothing is gained by recycling them)
     for (int k = 1; k <= 3; ++k) {
         TensorRef o = new_tensor(ar, N, 1, 1, dims[k]);
         Step s{};
@@ -388,7 +389,6 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
         net->steps.push_back(s);
         net->flops += 2.0 * N * dims[k - 1] * dims[k];
         net->t_fc[k - 1] = o; net->fc_w[k - 1] = s.w_off; net->fc_b[k - 1] = s.b_off;
-        done(f);
         f = o;
     }
     {
@@ -451,8 +451,8 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
     return net;
 }
 
-// What the online loop hangs behind the regressor's head: get_4_pts + get_Hs (+ the ring-head advance).  With the fused head
-// (head_chain.hip) they ride in its last phase; `done` tells the caller whether run_forward did them.
+// What the online loop hangs behind the regressor's head: get_4_pts + get_Hs (+ the ring-head advance).  With the shortened
+// head (head.hip) they ride in the output layer's launch; `done` tells the caller whether run_forward did them.
 struct MeshTail { int gh, gw; float lim; float* Hs; int* head_adv; int depth; bool done; };
 
 static int run_forward(const Net* net, const float* params, const float* fold, const float* x, float* theta,
@@ -460,15 +460,13 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
     float* splitk = ws + net->act_floats;
     const float* scale = fold;
     const float* shift = fold + net->G;
-    // the regressor's head (reduce_mean + FC chain [+ mesh]) as ONE launch where the shape and the device allow it
-    const bool chain = head_chain_supported(net->N, net->t_last.H * net->t_last.W, net->t_last.C, net->fc_dims,
-                                            mesh ? mesh->gh : 1, mesh ? mesh->gw : 1);
-    unsigned* sync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + net->act_floats * sizeof(float) + net->splitk_bytes);
+    // inference head, batch <= 8: reduce_mean finalize folded into fc_1, output layer + mesh as one launch (head.hip)
+    const bool fused_head = head_fused_supported(net->N, net->t_last.C, net->fc_dims);
     if (mesh) mesh->done = false;
     for (const Step& s : net->steps) {
         int rc = STABNET_OK;
         if (s.kind == S_PAD && skip_pad) continue;
-        if (s.kind == S_FC && chain) continue;
+        if (s.kind == S_FC && fused_head && (s.in_off == net->t_gap.off || s.out_off == EXT_OUT)) continue;   // fc_1 rides with the GAP, the output layer with the mesh
         const bool rec = (s.kind != S_CONV) && prof != nullptr && prof->begin(st);
         switch (s.kind) {
             case S_PAD:
@@ -501,29 +499,12 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
             }
             case S_POOL:
                 rc = launch_max_pool(ws + s.in_off, ws + s.out_off, s.N, s.H, s.W, s.C, s.Ho, s.Wo, s.k, s.stride, s.pt,
-                                     s.pl, s.obn_off >= 0 ? scale + s.obn_off : nullptr, s.obn_off >= 0 ? shift + s.obn_off : nullptr, st,
-                                     chain ? sync : nullptr);                 // (zeroes the fused head's phase counters)
+                                     s.pl, s.obn_off >= 0 ? scale + s.obn_off : nullptr, s.obn_off >= 0 ? shift + s.obn_off : nullptr, st);
                 break;
             case S_GAP:
-                if (chain) {
-                    HeadChainArgs a{};
-                    a.x = ws + s.in_off; a.scale = scale + s.bn_off; a.shift = shift + s.bn_off;
-                    a.N = s.N; a.HW = s.H * s.W; a.C = s.C;
-                    for (int k = 0; k < 4; ++k) { a.w[k] = params + net->fc_w[k]; a.b[k] = params + net->fc_b[k]; }
-                    a.n_theta = net->n_theta;
-                    a.partial = splitk;                                       // partials live in the split-K scratch
-                    a.gap = ws + s.out_off;
-                    for (int k = 0; k < 3; ++k) a.fc[k] = ws + net->t_fc[k].off;
-                    a.theta = theta;
-                    a.sync = sync;
-                    if (mesh) {
-                        a.gh = mesh->gh; a.gw = mesh->gw; a.lim = mesh->lim; a.Hs = mesh->Hs; a.head_adv = mesh->head_adv;
-                        a.depth = mesh->depth;
-                        mesh->done = true;
-                    } else {
-                        a.gh = a.gw = 1;
-                    }
-                    rc = launch_head_chain(a, st);
+                if (fused_head) {                                            // partial sums + fc_1 (partials in the split-K scratch)
+                    rc = launch_gap_fc1(ws + s.in_off, scale + s.bn_off, shift + s.bn_off, s.N, s.H * s.W, s.C, splitk, ws + s.out_off,
+                                        params + net->fc_w[0], params + net->fc_b[0], ws + net->t_fc[0].off, net->fc_dims[1], st);
                     break;
                 }
                 rc = launch_gap_bn_relu(ws + s.in_off, scale + s.bn_off, shift + s.bn_off, s.N, s.H * s.W, s.C,
@@ -541,13 +522,19 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
             if (s.kind == S_POOL) bytes = 4.0 * s.N * s.C * ((double)s.H * s.W + (double)s.Ho * s.Wo);
             if (s.kind == S_GAP) bytes = 4.0 * s.N * s.C * ((double)s.H * s.W + 1);
             if (s.kind == S_FC) bytes = 4.0 * ((double)s.K * s.Nout + (double)s.M * (s.K + s.Nout));
-            if (s.kind == S_GAP && chain) {                 // + the FC weights it streams
-                for (int k = 0; k < 4; ++k) bytes += 4.0 * net->fc_dims[k] * net->fc_dims[k + 1];
-                prof->end(st, PK_KERNEL_HEAD, 0.0, bytes);
-            } else
+            if (s.kind == S_GAP && fused_head) bytes += 4.0 * net->fc_dims[0] * net->fc_dims[1];      // + fc_1's weights
             prof->end(st, kmap[s.kind], s.kind == S_FC ? 2.0 * s.M * s.K * s.Nout : 0.0, bytes);
         }
         if (rc) return rc;
+    }
+    if (fused_head) {                                         // output_layer (+ mesh + ring-head advance) as one launch
+        const bool rec = prof != nullptr && prof->begin(st);
+        const int rc = launch_theta_mesh(ws + net->t_fc[2].off, params + net->fc_w[3], params + net->fc_b[3], net->N, net->n_theta, theta,
+                                         mesh ? mesh->gh : 1, mesh ? mesh->gw : 1, mesh ? mesh->lim : 0.f, mesh ? mesh->Hs : nullptr,
+                                         mesh ? mesh->head_adv : nullptr, mesh ? mesh->depth : 1, st);
+        if (rec) prof->end(st, PK_KERNEL_HEAD, 2.0 * net->N * 512 * net->n_theta, 4.0 * 512 * net->n_theta);
+        if (rc) return rc;
+        if (mesh) mesh->done = true;
     }
     return STABNET_OK;
 }
@@ -614,7 +601,7 @@ const char* stabnet_prof_kind_name(int kind) {
         case PK_KERNEL_GAP: return "gap_bn_relu_partial_kernel";
         case PK_KERNEL_FC: return "fc_kernel";
         case PK_KERNEL_MESH: return "mesh_homography_kernel";
-        case PK_KERNEL_HEAD: return "head_chain_kernel";
+        case PK_KERNEL_HEAD: return "theta_mesh_kernel";
         case PK_KERNEL_WARP: return "warp_sample_kernel";
         case PK_KERNEL_ASSEMBLE: return "stack_assemble_bordered_kernel";
         case PK_KERNEL_PUSH: return "ring_push_kernel";
@@ -703,8 +690,18 @@ int stabnet_net_num_launches(const void* netp) {
     const Net* net = static_cast<const Net*>(netp);
     if (!net) return -1;
     int n = 0;
-    for (const Step& s : net->steps) n += (s.kind == S_CONV && s.conv.splitk > 1) ? 2 : (s.kind == S_FC ? fc_launches(s.M) : 1);
+    // (shortened head: GAP partials + fc_1 = 2 launches, fc_2, fc_3, output layer [+ mesh] = 3; else 2 + 4 x fc_launches)
+    for (const Step& s : net->steps) n += (s.kind == S_CONV && s.conv.splitk > 1) ? 2 : (s.kind == S_FC ? fc_launches(s.M) : (s.kind == S_GAP ? 2 : 1));
+    if (head_fused_supported(net->N, net->t_last.C, net->fc_dims)) n -= 1 /* gap_finalize */ + (fc_launches(net->N) - 1) * 2;
     return n;
+}
+
+int stabnet_deploy_frame_launches(const void* netp, int grid_h, int grid_w) {
+    const Net* net = static_cast<const Net*>(netp);
+    if (!net) return -1;
+    (void)grid_h; (void)grid_w;
+    const bool fused = head_fused_supported(net->N, net->t_last.C, net->fc_dims) != 0;     // the mesh rides with the output layer
+    return stabnet_net_num_launches(netp) - 1 /* the stack assembly replaces the pad step */ + 1 + (fused ? 0 : 1) + 1;
 }
 
 /* Debug taps (valid after a forward only when the net was created with keep_activations=1):

@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const ColGroups G, long
             } else if (MODE == 1) {
                 const float4 v = *reinterpret_cast<const float4*>(x + r * C + c);
                 float4 d = *reinterpret_cast<const float4*>(g + r * C + c);
-                d.x = (v.x * sc.x + sh.x > 0.f) ? d.x : 0.f; d.y = (v.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
-                d.z = (v.z * sc.z + sh.z > 0.f) ? d.z : 0.f; d.w = (v.w * sc.w + sh.w > 0.f) ? d.w : 0.f;
+                d.x = (__builtin_fmaf(v.x, sc.x, sh.x) > 0.f) ? d.x : 0.f; d.y = (__builtin_fmaf(v.y, sc.y, sh.y) > 0.f) ? d.y : 0.f;   // the forward's own decision (fma + max in the conv prologue)
+                d.z = (__builtin_fmaf(v.z, sc.z, sh.z) > 0.f) ? d.z : 0.f; d.w = (__builtin_fmaf(v.w, sc.w, sh.w) > 0.f) ? d.w : 0.f;
                 a0.x += d.x; a0.y += d.y; a0.z += d.z; a0.w += d.w;
                 a1.x += d.x * (v.x - mu.x) * is.x; a1.y += d.y * (v.y - mu.y) * is.y;
                 a1.z += d.z * (v.z - mu.z) * is.z; a1.w += d.w * (v.w - mu.w) * is.w;
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnApply A, int 
     const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
     const float4 k1 = *reinterpret_cast<const float4*>(coef + c), c1 = *reinterpret_cast<const float4*>(coef + C + c);
     const float4 c2 = *reinterpret_cast<const float4*>(coef + 2 * C + c);
-    d.x = (v.x * sc.x + sh.x > 0.f) ? d.x : 0.f; d.y = (v.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
-    d.z = (v.z * sc.z + sh.z > 0.f) ? d.z : 0.f; d.w = (v.w * sc.w + sh.w > 0.f) ? d.w : 0.f;
+    d.x = (__builtin_fmaf(v.x, sc.x, sh.x) > 0.f) ? d.x : 0.f; d.y = (__builtin_fmaf(v.y, sc.y, sh.y) > 0.f) ? d.y : 0.f;   // the forward's own decision (fma + max in the conv prologue)
+    d.z = (__builtin_fmaf(v.z, sc.z, sh.z) > 0.f) ? d.z : 0.f; d.w = (__builtin_fmaf(v.w, sc.w, sh.w) > 0.f) ? d.w : 0.f;
     float4 o;
     o.x = k1.x * (d.x - c1.x - (v.x - mu.x) * is.x * c2.x);
     o.y = k1.y * (d.y - c1.y - (v.y - mu.y) * is.y * c2.y);

@@ -111,6 +111,9 @@ size_t stabnet_net_bn_channels(const void* net);
 size_t stabnet_net_workspace_bytes(const void* net);
 double stabnet_net_flops(const void* net);
 int stabnet_net_num_launches(const void* net);
+/* Kernel launches of one stabnet_deploy_frame pass (refine = 1) on the CURRENT device: stack assembly + the regressor's
+ * launches + (mesh, unless it rides with the output layer's launch: batch <= 8) + sampler-with-push; -1 on a null plan. */
+int stabnet_deploy_frame_launches(const void* net, int grid_h, int grid_w);
 int stabnet_net_activation_info(const void* net, const char* name, long* offset, int* dims4);
 
 /* slim batch_norm(is_training=False) folded to per-channel (scale, shift): fold = [G scales][G shifts],
@@ -163,7 +166,9 @@ int stabnet_prof_record_shape(const void* prof, int idx, int* shape4);
 const char* stabnet_prof_kind_name(int kind);
 
 /* ---- measurement helpers (bench.py: empirical peaks of the box beside the vendor peaks; not on the path) ---- */
-int stabnet_probe_mfma_f32(float* out /* blocks*256 floats */, int blocks, int iters, void* stream);
+int stabnet_probe_mfma_f32(float* out /* blocks*256 floats */, int blocks, int iters,
+                           unsigned long long* stamps /* optional, device [blocks][2]: {shader cycles, 100 MHz ticks} in the loop */,
+                           void* stream);
 double stabnet_probe_mfma_f32_flops(int blocks, int iters);
 int stabnet_probe_hbm_copy(const float* src, float* dst, long n_floats, void* stream);
 
