@@ -1301,6 +1301,32 @@ int stabnet_net_train_bn_offsets(const void* netp, long* scale_off, long* shift_
     return STABNET_OK;
 }
 
+/* Where the training forward left what its discrete decisions can be read from (tests force them onto the float64 autograd
+ * oracle): `what` = "bn:<channel offset>" -> the tensor that BN normalises (float offset, element count M*C);
+ * "fcx<k>", k = 0..3 -> input of FC layer k for the PAIR, [2N][dims[k]] in tower 0's workspace; "argmax" -> the max-pool argmax
+ * BYTES (float offset of their start, byte count); "pool" -> the pooled tensor. */
+int stabnet_net_train_debug_offset(const void* netp, const char* what, long* off, long* count) {
+    const Net* net = static_cast<const Net*>(netp);
+    SN_REQUIRE(net && what && off && count && net->keep_all, "train_debug_offset: bad arguments (needs a keep_activations plan)");
+    const TrainLayout L = train_layout(net);
+    const std::string w(what);
+    if (w.rfind("bn:", 0) == 0) {
+        const BnInfo* b = find_bn(net, atol(w.c_str() + 3));
+        SN_REQUIRE(b != nullptr, "train_debug_offset: no BN at channel offset %s", w.c_str() + 3);
+        *off = b->tensor_off; *count = b->M * b->C;
+        return STABNET_OK;
+    }
+    if (w.rfind("fcx", 0) == 0 && w.size() == 4 && w[3] >= '0' && w[3] <= '3') {
+        const int k = w[3] - '0';
+        *off = (long)L.fcx[k]; *count = 2L * net->N * net->fc_dims[k];
+        return STABNET_OK;
+    }
+    if (w == "argmax") { *off = (long)L.argmax; *count = (long)net->t_pool.size; return STABNET_OK; }
+    if (w == "pool") { *off = net->t_pool.off; *count = (long)net->t_pool.size; return STABNET_OK; }
+    stabnet_set_error("train_debug_offset: unknown item %s", what);
+    return STABNET_ERR_BAD_ARG;
+}
+
 /* slim L2 regularisers (s_net_bundle_nobm.py:324-325; resnet.py:35-37): value = sum_seg coef*0.5*sum w^2 added to
  * *loss_out (zero it first; may be NULL); grads[seg] += gscale*coef*w (grads may be NULL).  seg_* are DEVICE arrays. */
 int stabnet_weight_decay(const float* params, float* grads, const long* seg_off, const long* seg_len,

@@ -280,6 +280,12 @@ int stabnet_net_bn_grad_range(const void* net, long* lo, long* hi);
 /* Float offsets, inside a tower workspace, of the batch BN buffers [G] (scale, shift, mean, invstd) of the last forward. */
 int stabnet_net_train_bn_offsets(const void* net, long* scale_off, long* shift_off, long* mean_off, long* invstd_off);
 
+/* Debug view of a training workspace after a forward (tests read the forward's discrete decisions -- ReLU signs, max-pool
+ * argmax -- back from it): what = "bn:<channel offset>" (the tensor that BN normalises: float offset, M*C elements),
+ * "fcx0".."fcx3" (input of FC layer k of the PAIR, [2N][dims[k]], tower 0's workspace), "argmax" (float offset of the pool's
+ * argmax bytes, byte count), "pool". */
+int stabnet_net_train_debug_offset(const void* net, const char* what, long* off, long* count);
+
 /* slim L2 regularisers (REGULARIZATION_LOSSES, s_net_bundle_nobm.py:324-325; resnet.py:35-37): *loss_out +=
  * sum_seg coef*0.5*sum w^2 (NULL to skip), grads[seg] += gscale*coef*w (NULL to skip).  seg_* are DEVICE arrays.
  * workspace: 64*nseg floats (block partials of the value; may be NULL when loss_out is). */

@@ -8,6 +8,15 @@ be checked against.  tests/test_oracle_cpu.py checks this file's forward against
 Autodiff conventions reproduced (they decide the gradient): floor / int casts / comparisons carry no gradient, so
 sampler corners, `black_pix`, `warp_pts` indices and the z-sign are constants; clip_by_value / minimum / maximum pass
 gradient only where not saturated; gather back-propagates as scatter-add.
+
+DECISIONS.  The objective is piecewise smooth: ReLU signs, the max-pool arg-max, `black_pix`, the sampler's floor corners.
+A float32 forward and this float64 one can take different sides of such a decision when the deciding value sits within
+float32 rounding of its threshold; the two then differentiate DIFFERENT smooth pieces and their gradients differ by far more
+than rounding.  `decisions=` (train_objective) lets a test hand in the decisions the float32 forward under test really took
+(per tower: 'relu' {BN prefix | 'fc1'..'fc3' -> bool array}, 'pool_argmax' uint8 [N,Ho,Wo,C] = dy*3+dx, 'black' [N,H,W],
+'corners' (x0,y0,x1,y1)), so that both sides differentiate the same piece; `record=` collects this file's own decisions in the
+same format, so a test can name the ones that flipped.  Decisions that depend on INPUT data only (feature-loss pixel indices,
+the corners of `interpolate(., flow)`) are taken in float32 here, as the reference takes them.
 """
 from __future__ import annotations
 
@@ -95,8 +104,29 @@ def _sample(im, x, y, corners=None):
     return (wa * Ia + wb * Ib + wc * Ic + wd * Id).reshape(N, H, W, C)
 
 
-def transformer(U, pts2, cfg, corners=None):
-    """spatial_transformer3.py:218-301 -> (out [N,H,W,C], black [N,H,W], maps [N,H,W,2])."""
+def corners_f32(x, y, H, W):
+    """The sampler's clipped floor corners decided in float32 with the reference's op order (spatial_transformer3.py:81-93);
+    x, y: float arrays [N,H,W] (normalised coordinates)."""
+    x = np.asarray(x, np.float32)
+    y = np.asarray(y, np.float32)
+    xp = (x + np.float32(1.0)) * np.float32(W) / np.float32(2.0)
+    yp = (y + np.float32(1.0)) * np.float32(H) / np.float32(2.0)
+    x0 = np.clip(np.floor(xp), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int64)
+    y0 = np.clip(np.floor(yp), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int64)
+    return (np.clip(x0, 0, W - 1), np.clip(y0, 0, H - 1), np.clip(x0 + 1, 0, W - 1), np.clip(y0 + 1, 0, H - 1))
+
+
+def _own_corners(x, y, H, W):
+    xp = (x.detach() + 1.0) * W / 2.0
+    yp = (y.detach() + 1.0) * H / 2.0
+    x0 = torch.floor(xp).clamp(-2 ** 31, 2 ** 31 - 1).long()
+    y0 = torch.floor(yp).clamp(-2 ** 31, 2 ** 31 - 1).long()
+    return tuple(a.numpy() for a in (x0.clamp(0, W - 1), y0.clamp(0, H - 1), (x0 + 1).clamp(0, W - 1), (y0 + 1).clamp(0, H - 1)))
+
+
+def transformer(U, pts2, cfg, corners=None, black=None, record=None):
+    """spatial_transformer3.py:218-301 -> (out [N,H,W,C], black [N,H,W], maps [N,H,W,2]).  corners / black: decisions of the
+    forward under test (module docstring); record: dict that receives this evaluation's own."""
     N, H, W, C = U.shape
     gh, gw = cfg.grid_h, cfg.grid_w
     Hs = get_Hs(pts2, cfg)
@@ -122,15 +152,23 @@ def transformer(U, pts2, cfg, corners=None):
         yrows.append(torch.cat(yr, dim=2))
     x_map = torch.cat(xrows, dim=1)
     y_map = torch.cat(yrows, dim=1)
-    black = ((x_map < -1) | (x_map > 1) | (y_map < -1) | (y_map > 1)).to(DT).detach()
+    own_black = ((x_map < -1) | (x_map > 1) | (y_map < -1) | (y_map > 1)).detach()
+    if record is not None:
+        record['black'] = own_black.numpy().copy()
+        record['corners'] = _own_corners(x_map, y_map, H, W)
+    black = (torch.as_tensor(np.asarray(black).reshape(N, H, W) != 0) if black is not None else own_black).to(DT)
     out = _sample(U, x_map, y_map, corners)
     return out, black, torch.stack([x_map, y_map], dim=3), Hs
 
 
 def interpolate(im, x, y, corners=None):
-    """spatial_transformer.py:200-281."""
+    """spatial_transformer.py:200-281.  The maps are input data (the optical flow): their floor corners are float32 decisions of
+    the reference, taken here in float32 too unless given."""
     N, H, W, C = im.shape
-    return _sample(im, x.reshape(N, H, W), y.reshape(N, H, W), corners)
+    x, y = x.reshape(N, H, W), y.reshape(N, H, W)
+    if corners is None:
+        corners = corners_f32(x.detach().numpy(), y.detach().numpy(), H, W)
+    return _sample(im, x, y, corners)
 
 
 # ---- losses ------------------------------------------------------------------------------------------------
@@ -242,37 +280,66 @@ def _bn(x, p, prefix, cfg, training, batch_stats=None):
     return x * inv + (beta - mean * inv)
 
 
-def resnet_v2_50(x, p, cfg, training, batch_stats=None):
-    R = 'resnet_v2_50/'
-    net = _conv_same(x, p[R + 'conv1/weights'], 2, p[R + 'conv1/biases'])
+def _relu(y, key, dec, rec):
+    """relu(y).  dec['relu'][key] (bool, y's shape): the sign decisions of the forward under test replace this evaluation's own
+    (y * mask has relu's derivative wherever the two agree); rec['relu'][key] receives this evaluation's own."""
+    if rec is not None:
+        rec.setdefault('relu', {})[key] = (y.detach() > 0).numpy()
+    if dec is not None and key in dec.get('relu', {}):
+        return y * torch.as_tensor(np.asarray(dec['relu'][key]).reshape(tuple(y.shape)) != 0).to(DT)
+    return torch.relu(y)
+
+
+def _max_pool_3x3s2(net, dec, rec):
+    """slim max_pool2d(3, stride 2, 'SAME') on NHWC; dec['pool_argmax'] (uint8 [N,Ho,Wo,C], dy*3+dx in the window, first maximum
+    in scan order) replaces the arg-max of this evaluation."""
     ph = O._same_pads(net.shape[1], 3, 2)
     pw = O._same_pads(net.shape[2], 3, 2)
     nc = Fnn.pad(net.permute(0, 3, 1, 2), (pw[0], pw[1], ph[0], ph[1]), value=-math.inf)
-    net = Fnn.max_pool2d(nc, 3, 2).permute(0, 2, 3, 1)
+    pooled, idx = Fnn.max_pool2d(nc, 3, 2, return_indices=True)
+    N, C, Ho, Wo = pooled.shape
+    Wp = nc.shape[3]
+    oy = torch.arange(Ho)[None, None, :, None]
+    ox = torch.arange(Wo)[None, None, None, :]
+    if rec is not None:
+        iy, ix = idx // Wp, idx % Wp
+        rec['pool_argmax'] = ((iy - 2 * oy) * 3 + (ix - 2 * ox)).permute(0, 2, 3, 1).numpy().astype(np.uint8)
+    if dec is not None and 'pool_argmax' in dec:
+        am = torch.as_tensor(np.asarray(dec['pool_argmax']).reshape(N, Ho, Wo, C).astype(np.int64)).permute(0, 3, 1, 2)
+        # the kernel's window starts at (2 oy - pad_top, 2 ox - pad_left): in the padded image that is (2 oy, 2 ox)
+        flat = (2 * oy + am // 3) * Wp + (2 * ox + am % 3)
+        pooled = nc.reshape(N, C, -1).gather(2, flat.reshape(N, C, -1)).reshape(N, C, Ho, Wo)
+    return pooled.permute(0, 2, 3, 1)
+
+
+def resnet_v2_50(x, p, cfg, training, batch_stats=None, dec=None, rec=None):
+    R = 'resnet_v2_50/'
+    net = _conv_same(x, p[R + 'conv1/weights'], 2, p[R + 'conv1/biases'])
+    net = _max_pool_3x3s2(net, dec, rec)
     for (bname, depth, dbn, units, bstride) in O.RESNET_V2_50_BLOCKS:
         for u in range(1, units + 1):
             stride = bstride if u == units else 1
             S = R + '%s/unit_%d/bottleneck_v2/' % (bname, u)
             depth_in = net.shape[3]
-            preact = torch.relu(_bn(net, p, S + 'preact', cfg, training, batch_stats))
+            preact = _relu(_bn(net, p, S + 'preact', cfg, training, batch_stats), S + 'preact', dec, rec)
             if depth == depth_in:
                 shortcut = net if stride == 1 else net[:, ::stride, ::stride, :]
             else:
                 shortcut = _conv(preact, p[S + 'shortcut/weights'], stride, bias=p[S + 'shortcut/biases'])
             r = _conv(preact, p[S + 'conv1/weights'], 1)
-            r = torch.relu(_bn(r, p, S + 'conv1/BatchNorm', cfg, training, batch_stats))
+            r = _relu(_bn(r, p, S + 'conv1/BatchNorm', cfg, training, batch_stats), S + 'conv1/BatchNorm', dec, rec)
             r = _conv_same(r, p[S + 'conv2/weights'], stride)
-            r = torch.relu(_bn(r, p, S + 'conv2/BatchNorm', cfg, training, batch_stats))
+            r = _relu(_bn(r, p, S + 'conv2/BatchNorm', cfg, training, batch_stats), S + 'conv2/BatchNorm', dec, rec)
             r = _conv(r, p[S + 'conv3/weights'], 1, bias=p[S + 'conv3/biases'])
             net = shortcut + r
-    return torch.relu(_bn(net, p, R + 'postnorm', cfg, training, batch_stats))
+    return _relu(_bn(net, p, R + 'postnorm', cfg, training, batch_stats), R + 'postnorm', dec, rec)
 
 
-def get_resnet(x_tensor, p, cfg, training, batch_stats=None):
-    feat = resnet_v2_50(x_tensor, p, cfg, training, batch_stats)
+def get_resnet(x_tensor, p, cfg, training, batch_stats=None, dec=None, rec=None):
+    feat = resnet_v2_50(x_tensor, p, cfg, training, batch_stats, dec, rec)
     g = feat.mean(dim=(1, 2))
     for k in (1, 2, 3):
-        g = torch.relu(g @ p['fc/fc/fc_%d/weights' % k] + p['fc/fc/fc_%d/biases' % k])
+        g = _relu(g @ p['fc/fc/fc_%d/weights' % k] + p['fc/fc/fc_%d/biases' % k], 'fc%d' % k, dec, rec)
     theta = g @ p['fc/fc_weights'] + p['fc/fc_bias']
     id2 = theta.abs().mean() * cfg.id_mul
     return theta, id2, id2
@@ -288,10 +355,11 @@ def regu_loss(p, cfg):
     return tot
 
 
-def tower_losses(theta, x_cur, y, matches, mask, cfg, use_black_loss=1.0):
+def tower_losses(theta, x_cur, y, matches, mask, cfg, use_black_loss=1.0, dec=None, rec=None):
     """Everything of inference_stable_net downstream of theta (s_net_bundle_nobm.py:304-352)."""
     pts1, pts2 = get_4_pts(theta, cfg)
-    out, black, flow, Hs = transformer(x_cur, pts2, cfg)
+    out, black, flow, Hs = transformer(x_cur, pts2, cfg, corners=(dec or {}).get('corners'), black=(dec or {}).get('black'),
+                                       record=rec)
     bp = get_black_pos(pts1, cfg)
     black_pos_loss = (bp * bp * use_black_loss).mean()
     return {'pts1': pts1, 'pts2': pts2, 'output': out, 'black_pix': black, 'flow': flow, 'Hs': Hs,
@@ -308,9 +376,9 @@ def tower_total(id_loss, id2_loss, L, regu, cfg, use_theta_only=0.0):
 
 
 def train_objective(p, batch, cfg, use_temp_loss=1.0, use_black_loss=1.0, use_theta_only=0.0, training=True,
-                    batch_stats=None):
+                    batch_stats=None, decisions=None, record=None):
     """train_bundle_nobm.py:107-142: two towers sharing weights + temporal loss.  p: name -> torch tensor (TF layout).
-    Returns (total, parts dict)."""
+    decisions / record: {'1': {...}, '2': {...}} per tower, see the module docstring.  Returns (total, parts dict)."""
     parts = {}
     regu = regu_loss(p, cfg)
     towers = []
@@ -318,11 +386,13 @@ def train_objective(p, batch, cfg, use_temp_loss=1.0, use_black_loss=1.0, use_th
         x = t(batch['x' + k])
         cur = 2 * cfg.before_ch if cfg.input_mask else cfg.before_ch
         bs = {} if batch_stats is not None else None
-        theta, id_loss, id2_loss = get_resnet(x, p, cfg, training, bs)
+        dec = decisions.get(k) if decisions is not None else None
+        rec = record.setdefault(k, {}) if record is not None else None
+        theta, id_loss, id2_loss = get_resnet(x, p, cfg, training, bs, dec, rec)
         if batch_stats is not None:
             batch_stats[k] = bs
         L = tower_losses(theta, x[..., cur:cur + 1], t(batch['y' + k]), t(batch['matches' + k]), t(batch['mask' + k]),
-                         cfg, use_black_loss)
+                         cfg, use_black_loss, dec, rec)
         L['theta'] = theta
         L['total'] = tower_total(id_loss, id2_loss, L, regu, cfg, use_theta_only)
         towers.append(L)

@@ -6,11 +6,14 @@
                                                        gradient of every parameter tensor vs float64 autograd
 (configs[3] and the 8-stream form of configs[4] need 8 GPUs; one stream per GPU is what each of them runs.)"""
 import os
+import sys
 import zlib
 
 import numpy as np
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import stabnet_oracle as O
 from oracle import torch_ref as T
@@ -173,30 +176,37 @@ def test_training_step_8x288x512_matches_oracles(cuda):
     total = float(r[0]["total_loss"]) + float(r[1]["total_loss"]) + float(temp) * cfg.temp_mul      # train_bundle_nobm.py:142
     assert lo["total_loss"] == pytest.approx(total, rel=2e-3)
 
-    # ---- backward vs float64 autograd of the same objective, every trainable tensor
+    # ---- backward vs float64 autograd of the same objective, every trainable tensor (tests/test_train_gpu.py explains the two
+    #      checks: per element against the float64 gradient of the piece the GPU forward really took -- its discrete decisions
+    #      forced onto the oracle --, whole gradient against the un-forced float64 evaluation)
+    from _decisions import flips, gpu_decisions, gradient_errors
     pt = {k: T.t(v, requires_grad=True) for k, v in P.items()}
-    tot64, _ = T.train_objective(pt, b, ocfg, 1.0, 1.0, 0.0, training=True)
+    own = {}
+    tot64, _ = T.train_objective(pt, b, ocfg, 1.0, 1.0, 0.0, training=True, record=own)
     tot64.backward()
     assert lo["total_loss"] == pytest.approx(float(tot64), rel=2e-3)
     want_flat = tr.plan.pack({k: (pt[k].grad.numpy() if pt[k].grad is not None else np.zeros(P[k].shape)) for k in P})[:tr.nt]
-    gmax = np.abs(want_flat).max()
-    worst_abs = worst_l2 = 0.0
-    for name, off, kind, dims, aux in tr.plan.table:
-        if kind in (4, 5):
-            continue
-        n = int(np.prod([d for d in dims if d > 0]))
-        gg, ww = got_flat[off:off + n].astype(np.float64), want_flat[off:off + n].astype(np.float64)
-        scale = max(np.abs(ww).max(), 1e-5 * gmax)
-        err = np.abs(gg - ww).max() / scale
-        l2 = np.linalg.norm(gg - ww) / max(np.linalg.norm(ww), 1e-5 * gmax * np.sqrt(n))
-        worst_abs, worst_l2 = max(worst_abs, err), max(worst_l2, l2)
-        # float32 against float64 through 53 convs / 49 batch-stat BNs at 2.4 M pixels per tower: measured worst single
-        # element 3.7e-2 .. 4.7e-2 of its tensor's gradient scale (a few isolated elements), worst tensor 5.4e-3 .. 6.4e-3 in
-        # relative L2, whole gradient 5.3e-4 .. 5.7e-4 (the two figures: conv of both towers as one launch / one launch per tower);
-        # a 1e-7 relative change of the input moves the float32 gradient by 6.5e-4 (tests/test_train_gpu.py explains why)
-        assert err < 1e-1, "%s: element err %g (scale %g)" % (name, err, scale)
-        assert l2 < 1e-2, "%s: relative L2 err %g" % (name, l2)
-    print('MEASURED worst element %.3e worst tensor L2 %.3e whole L2 %.3e' % (worst_abs, worst_l2, np.linalg.norm(got_flat - want_flat) / np.linalg.norm(want_flat)))
-    assert np.linalg.norm(got_flat - want_flat) / np.linalg.norm(want_flat) < 2e-3       # measured 5.7e-4
+    del pt
+    dec = gpu_decisions(tr)
+    flipped = flips(dec, own)
+    del own
+    print("DECISIONS that differ between the float32 forward and float64:", flipped)
+    pf = {k: T.t(v, requires_grad=True) for k, v in P.items()}
+    totf, _ = T.train_objective(pf, b, ocfg, 1.0, 1.0, 0.0, training=True, decisions=dec)
+    totf.backward()
+    forced_flat = tr.plan.pack({k: (pf[k].grad.numpy() if pf[k].grad is not None else np.zeros(P[k].shape)) for k in P})[:tr.nt]
+    del pf, dec
+    worst_abs, worst_l2, whole, rows = gradient_errors(tr.plan, got_flat, forced_flat)
+    print('MEASURED (decisions forced) worst element %.3e worst tensor L2 %.3e whole L2 %.3e' % (worst_abs, worst_l2, whole))
+    for name, err, l2 in rows:
+        # float32 against float64 through 53 convs / 49 batch-stat BNs at 2.4 M pixels per tower, same smooth piece on both sides
+        # measured: ~70 ReLU signs of 2 x 350 M differ (all within float32 rounding of zero); forced: worst element 7.4e-3, worst
+        # tensor 2.6e-3, whole gradient 6.3e-5 (un-forced: 6.5e-2 / 5.2e-3 / 5.8e-4)
+        assert err < 2e-2, "%s: element err %g with the forward's decisions forced" % (name, err)
+        assert l2 < 5e-3, "%s: relative L2 err %g with the forward's decisions forced" % (name, l2)
+    assert whole < 5e-4, whole
+    u_abs, u_l2, whole_u, _ = gradient_errors(tr.plan, got_flat, want_flat)
+    print('MEASURED (un-forced) worst element %.3e worst tensor L2 %.3e whole L2 %.3e' % (u_abs, u_l2, whole_u))
+    assert whole_u < 2e-3, whole_u                                                      # measured 5.7e-4
     cos = float(np.dot(got_flat, want_flat) / (np.linalg.norm(got_flat) * np.linalg.norm(want_flat)))
     assert cos > 1 - 1e-5, cos

@@ -1,8 +1,13 @@
 """GPU: one full siamese training step (two towers, batch-stat BN, warp, all losses, temporal loss, backward, weight
 decay, Adam) against the torch float64 autograd oracle of the reference objective (train_bundle_nobm.py:107-160)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import stabnet_oracle as O
 from oracle import torch_ref as T
@@ -28,8 +33,8 @@ def test_training_step_matches_autograd_oracle(cuda):
     gates = {"use_theta_loss": 1, "use_temp_loss": 1, "use_black_loss": 1, "use_theta_only": 0}
 
     pt = {k: T.t(v, requires_grad=True) for k, v in P.items()}
-    stats = {}
-    total, parts = T.train_objective(pt, b, ocfg, 1.0, 1.0, 0.0, training=True, batch_stats=stats)
+    stats, own = {}, {}
+    total, parts = T.train_objective(pt, b, ocfg, 1.0, 1.0, 0.0, training=True, batch_stats=stats, record=own)
     total.backward()
     want_g = {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in pt.items()}
 
@@ -48,39 +53,39 @@ def test_training_step_matches_autograd_oracle(cuda):
     assert lo["tower1"]["img_loss"] == pytest.approx(float(parts["tower1"]["img"]) * cfg.img_mul, rel=2e-3)
     assert lo["tower2"]["feature_loss"] == pytest.approx(float(parts["tower2"]["feature"]), rel=2e-3)
 
-    # backward: every trainable tensor, error relative to that tensor's gradient scale
+    # backward: every trainable tensor, error relative to that tensor's gradient scale.
+    # The objective is piecewise smooth (ReLU signs, max-pool arg-max, `black_pix` = a strict comparison of the warp map with +-1,
+    # the sampler's floor corners): a float32 forward whose pre-activations differ from the float64 ones in the 7th digit can
+    # take the other side of such a decision, and then the two sides differentiate DIFFERENT smooth pieces.  So the gradient is
+    # checked twice: (a) against the float64 autograd of the piece the GPU forward really took -- its decisions are read back
+    # from the training workspace and forced onto the oracle (tests/_decisions.py, oracle/torch_ref.py DECISIONS) -- with the
+    # tight per-element bar; (b) against the un-forced float64 gradient with the whole-gradient bars (a flipped decision moves
+    # single elements by several per cent of their tensor's scale, the whole gradient by ~1e-3).
+    from _decisions import flips, gpu_decisions, gradient_errors
     got_flat = tr.grad_flat().cpu().numpy()
     want_flat = tr.plan.pack({k: want_g[k] for k in P})[:tr.nt]
-    # What the bars below allow for.  The objective is not smooth: `black_pix` is a strict comparison of the warp map with +-1
-    # (spatial_transformer3.py:284-286), the feature loss rounds pixel coordinates (s_net_bundle_nobm.py:218-221), ReLU masks and
-    # the max-pool argmax are discrete.  A float32 evaluation whose theta differs from the float64 one in the 7th digit can take
-    # the other side of such a decision: measured here (tools/scratch/pairfwd_compare.py, this configuration), forcing another
-    # split-K on every convolution moves the whole gradient by 1.5e-4 (relative L2) -- and both a 1e-7 relative change of the input
-    # and the lockstep forward that runs a conv of both towers as ONE launch move it by the SAME 2.2e-3, i.e. the same discrete
-    # decision flips (black-pixel counts and feature loss unchanged, img_loss of tower 2 changes in its 6th digit: what is left
-    # is a sampler cell boundary -- d/d map of a bilinear sample jumps there -- or a ReLU / arg-max choice).  So the error against
-    # float64 is 1.7e-4 on one side of that decision and 2.4e-3 on the other; at 8 x 288 x 512 (tests/test_baseline_sizes_gpu.py),
-    # where one pixel weighs 24x less, both variants measure 5.3e-4 .. 5.7e-4.
-    gmax = np.abs(want_flat).max()
-    worst_abs = worst_l2 = 0.0
-    for name, off, kind, dims, aux in tr.plan.table:
-        if kind in (4, 5):
-            continue
-        n = int(np.prod([d for d in dims if d > 0]))
-        gg, ww = got_flat[off:off + n].astype(np.float64), want_flat[off:off + n].astype(np.float64)
-        # tensors whose gradient is analytically ~0 (e.g. a bias in front of a batch-stat BN) are judged against the
-        # global gradient scale instead of their own
-        scale = max(np.abs(ww).max(), 1e-5 * gmax)
-        err = np.abs(gg - ww).max() / scale
-        l2 = np.linalg.norm(gg - ww) / max(np.linalg.norm(ww), 1e-5 * gmax * np.sqrt(n))
-        worst_abs, worst_l2 = max(worst_abs, err), max(worst_l2, l2)
-        assert err < 1.5e-1, "%s: element err %g (scale %g)" % (name, err, scale)      # measured 1.4e-2 .. 8.4e-2 (the two sides, see above)
-        assert l2 < 2e-2, "%s: relative L2 err %g" % (name, l2)                         # measured 3.6e-3 .. 8.7e-3
-    whole = np.linalg.norm(got_flat - want_flat) / np.linalg.norm(want_flat)
-    print("MEASURED worst element %.3e worst tensor L2 %.3e whole L2 %.3e" % (worst_abs, worst_l2, whole))
-    assert whole < 5e-3, whole                                                          # measured 1.7e-4 .. 2.4e-3 (see above)
+    dec = gpu_decisions(tr)
+    flipped = flips(dec, own)
+    print("DECISIONS that differ between the float32 forward and float64:", flipped)
+    assert sum(n for _, _, n, _ in flipped) <= 200, flipped          # a handful of rounding-level flips, not a systematic difference
+    pf = {k: T.t(v, requires_grad=True) for k, v in P.items()}
+    total_f, _ = T.train_objective(pf, b, ocfg, 1.0, 1.0, 0.0, training=True, decisions=dec)
+    total_f.backward()
+    forced_flat = tr.plan.pack({k: (pf[k].grad.numpy() if pf[k].grad is not None else np.zeros(P[k].shape)) for k in P})[:tr.nt]
+    worst_abs, worst_l2, whole, rows = gradient_errors(tr.plan, got_flat, forced_flat)
+    print("MEASURED (decisions forced) worst element %.3e worst tensor L2 %.3e whole L2 %.3e" % (worst_abs, worst_l2, whole))
+    # measured: ONE decision differs at this size -- a ReLU sign in tower 2, block3/unit_2/preact (1 of 49 152) --; with it forced:
+    # worst element 1.3e-2, worst tensor 4.0e-3, whole gradient 8.3e-6 (un-forced: 8.4e-2 / 8.7e-3 / 2.4e-3)
+    for name, err, l2 in rows:
+        assert err < 2e-2, "%s: element err %g with the forward's decisions forced" % (name, err)
+        assert l2 < 6e-3, "%s: relative L2 err %g with the forward's decisions forced" % (name, l2)
+    assert whole < 1e-4, whole
+    # (b) un-forced: whole-gradient agreement
+    u_abs, u_l2, whole_u, _ = gradient_errors(tr.plan, got_flat, want_flat)
+    print("MEASURED (un-forced) worst element %.3e worst tensor L2 %.3e whole L2 %.3e" % (u_abs, u_l2, whole_u))
+    assert whole_u < 5e-3, whole_u                                                      # measured 1.7e-4 .. 2.4e-3 (a flip or not)
     cos = float(np.dot(got_flat, want_flat) / (np.linalg.norm(got_flat) * np.linalg.norm(want_flat)))
-    assert cos > 1 - 1e-5, "gradient cosine %r, worst tensor element err %g" % (cos, worst_abs)
+    assert cos > 1 - 1e-5, "gradient cosine %r" % cos
 
     # batch-statistics BN moving averages (decay 0.997), both towers applied
     q = tr.plan.unpack(tr.params.cpu().numpy())
@@ -128,7 +133,11 @@ def test_theta_only_phase_and_gates(cuda):
 
 
 def test_loss_decreases_on_a_fixed_batch(cuda):
-    """End-to-end sanity of the optimiser loop: 25 Adam steps on one fixed batch reduce the total loss, reproducibly."""
+    """End-to-end sanity of the optimiser loop: 25 Adam steps on one fixed batch reduce the total loss, reproducibly.
+    The learning rate is the reference's 2e-5 (configs/v2_93.py:6).  An earlier version of this test used 2e-4 to make the
+    decrease faster; that is 10x the reference's step on a TWO-sample batch whose batch-norm statistics move with every
+    update, and the trajectory went 15.8 -> 8.1 -> 19.6 (not a bug of the step: the same happens in float64).  At the
+    reference's rate the loss falls monotonically."""
     from stabnet_amd.config import Config
     from stabnet_amd.train import Trainer
     from stabnet_amd import synthetic
