@@ -193,15 +193,24 @@ static int launch_one_nb(const ConvArgs& a, hipStream_t st) {
 
 static thread_local int g_bf16_operands = 0;      // set by conv_launch for the duration of one launch (see conv.h)
 
+// Which instantiation a register-staged launch runs: (NBUF, BF16) -- one rule for the launcher and for the profiler's kernel name.
+// 1x1 launches over the large maps (block 1 at 720p: M = 57 600) are bandwidth / epilogue shaped: ONE LDS stage (18 KB, twice
+// the resident workgroups) beats the double-buffered loop there (30.4 -> 28.8 us, 33.7 -> 32.2 us); below that it loses 0.3 us.
+// The bf16-operand variant exists for the inference tile (64 x 64 x 32) only.
+static void igemm_variant(const ConvArgs& a, int bm, int bn, int bk, int mode, int& nbuf_out, int& bf16_out) {
+    static const int nbuf = env_int("STABNET_CONV_NBUF", 0);          // 0: the rule; 1 / 2: forced
+    bf16_out = (g_bf16_operands && bm == 64 && bn == 64 && bk == 32) ? 1 : 0;
+    const bool one_stage = nbuf == 1 || (nbuf == 0 && mode == 0 && bm == 64 && bn == 64 && a.M >= 32768);
+    nbuf_out = (!bf16_out && one_stage) ? 1 : 2;
+}
+
 template <int BM, int BN, int BK, int WM, int WN, int MODE>
 static int launch_one_t(const ConvArgs& a, hipStream_t st) {
-    static const int nbuf = env_int("STABNET_CONV_NBUF", 0);          // 0: the rule below; 1 / 2: forced
-    if constexpr (BM == 64 && BN == 64 && BK == 32)           // the bf16-operand variant exists for the inference tile only
-        if (g_bf16_operands) return launch_one_nb<BM, BN, BK, WM, WN, MODE, 2, 1>(a, st);
-    // 1x1 launches over the large maps (block 1 at 720p: M = 57 600) are bandwidth / epilogue shaped: ONE LDS stage (18 KB, twice
-    // the resident workgroups) beats the double-buffered loop there (30.4 -> 28.8 us, 33.7 -> 32.2 us); below that it loses 0.3 us
-    const bool one_stage = nbuf == 1 || (nbuf == 0 && MODE == 0 && BM == 64 && BN == 64 && a.M >= 32768);
-    return one_stage ? launch_one_nb<BM, BN, BK, WM, WN, MODE, 1>(a, st) : launch_one_nb<BM, BN, BK, WM, WN, MODE, 2>(a, st);
+    int nbuf, bf16;
+    igemm_variant(a, BM, BN, BK, MODE, nbuf, bf16);
+    if constexpr (BM == 64 && BN == 64 && BK == 32)
+        if (bf16) return launch_one_nb<BM, BN, BK, WM, WN, MODE, 2, 1>(a, st);
+    return nbuf == 1 ? launch_one_nb<BM, BN, BK, WM, WN, MODE, 1>(a, st) : launch_one_nb<BM, BN, BK, WM, WN, MODE, 2>(a, st);
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
@@ -280,7 +289,14 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands
         else rc = launch_one<64, 64, 16, 32, 32>(a, st);
     }
     const int mode = (a.up > 1 || a.rowrun) ? 2 : (a.pad == 0 ? 0 : 1);
-    if (rec) prof->end(st, ring ? PK_KERNEL_CONV_RING + mode + (bf16_operands ? 3 : 0) : PK_KERNEL_CONV_BASE + mode * 6 + t * 2 + (bk32 ? 1 : 0), 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
+    int kind = PK_KERNEL_CONV_RING + mode + (bf16_operands ? 3 : 0);
+    if (!ring) {                                                  // + 18 for the one-stage (NBUF = 1), + 36 for the bf16-operand instantiation
+        int bm, bn, nbuf, bf16;
+        tile_dims(t, bm, bn);
+        igemm_variant(a, bm, bn, bk32 ? 32 : 16, mode, nbuf, bf16);
+        kind = PK_KERNEL_CONV_BASE + mode * 6 + t * 2 + (bk32 ? 1 : 0) + (nbuf == 1 ? 18 : 0) + (bf16 ? 36 : 0);
+    }
+    if (rec) prof->end(st, kind, 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
                        4.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.K * a.Cout + (double)a.M * a.Cout * a.splitk),
                        a.M, a.Cout, a.K, a.splitk);
     if (rc) return rc;

@@ -13,6 +13,8 @@
 #include <vector>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 
 #include "conv.h"
 #include "layers.h"
@@ -125,6 +127,22 @@ struct Net {
     int feat_H = 0, feat_W = 0;
     struct Tap { std::string name; long off; int N, H, W, C; };
     std::vector<Tap> taps;
+    // Which training forward filled a workspace last (host-side, in enqueue order): the lockstep forward keeps the FC-head
+    // activations of BOTH towers in the pair's first workspace, the single-tower forward in its own -- a backward of the other
+    // kind would read rows that were never written.  value: {kind, partner}; kind 1 = stabnet_tower_fwd_train, 2 / 3 = first /
+    // second workspace of stabnet_towers_fwd_train.
+    struct FwdStamp { int kind; const void* partner; };
+    mutable std::mutex stamp_mu;
+    mutable std::unordered_map<const void*, FwdStamp> fwd_stamp;
+    void stamp(const void* ws, int kind, const void* partner) const {
+        std::lock_guard<std::mutex> g(stamp_mu);
+        fwd_stamp[ws] = FwdStamp{kind, partner};
+    }
+    FwdStamp stamp_of(const void* ws) const {
+        std::lock_guard<std::mutex> g(stamp_mu);
+        auto it = fwd_stamp.find(ws);
+        return it == fwd_stamp.end() ? FwdStamp{0, nullptr} : it->second;
+    }
 
     size_t add_param(const std::string& name, int kind, int d0, int d1, int d2, int d3, int aux) {
         ParamEntry e;
@@ -626,12 +644,18 @@ const char* stabnet_prof_kind_name(int kind) {
     if (kind == PK_KERNEL_CONV_RING + 3) return "conv_ring_f32_kernel<0, 1>";
     if (kind == PK_KERNEL_CONV_RING + 4) return "conv_ring_f32_kernel<1, 1>";
     if (kind == PK_KERNEL_CONV_RING + 5) return "conv_ring_f32_kernel<2, 1>";
-    if (kind >= PK_KERNEL_CONV_BASE && kind < PK_KERNEL_CONV_BASE + 18) {
-        // names as rocprofv3 prints the template instantiation: <BM, BN, BK, WM, WN, MODE, NBUF>
+    if (kind >= PK_KERNEL_CONV_BASE && kind < PK_KERNEL_CONV_BASE + 72) {
+        // names as rocprofv3 prints the template instantiation: <BM, BN, BK, WM, WN, MODE, NBUF, BF16>
+        // (kind = base + MODE*6 + tile*2 + (BK==32) + 18 if NBUF == 1 + 36 if BF16, conv.hip)
         static thread_local char buf[96];
-        const int k = kind - PK_KERNEL_CONV_BASE, mode = k / 6, t = (k % 6) / 2, bk = (k & 1) ? 32 : 16;
+        int k = kind - PK_KERNEL_CONV_BASE;
+        const int bf16 = k >= 36 ? 1 : 0;
+        k -= 36 * bf16;
+        const int nbuf = k >= 18 ? 1 : 2;
+        k -= (nbuf == 1) ? 18 : 0;
+        const int mode = k / 6, t = (k % 6) / 2, bk = (k & 1) ? 32 : 16;
         const int bm = (t == 2) ? 64 : 128, bn = (t == 0) ? 128 : 64, wm = (t == 2) ? 32 : 64, wn = (t == 0) ? 64 : 32;
-        snprintf(buf, sizeof(buf), "conv_igemm_f32_kernel<%d, %d, %d, %d, %d, %d, 2, 0>", bm, bn, bk, wm, wn, mode);
+        snprintf(buf, sizeof(buf), "conv_igemm_f32_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", bm, bn, bk, wm, wn, mode, nbuf, bf16);
         return buf;
     }
     return "?";
@@ -1201,6 +1225,7 @@ int stabnet_tower_fwd_train(const void* netp, float* params, const float* x_tens
     if (int rc = sn_check_device(params, "tower_fwd_train: params", (hipStream_t)stream)) return rc;
     if (int rc = sn_check_device(x_tensor, "tower_fwd_train: x_tensor", (hipStream_t)stream)) return rc;
     float* ws[1] = {static_cast<float*>(workspace)};
+    net->stamp(workspace, 1, nullptr);
     return run_forward_train(net, params, 1, &x_tensor, &theta, ws, bn_eps, bn_decay, (hipStream_t)stream, static_cast<Prof*>(prof));
 }
 
@@ -1220,6 +1245,8 @@ int stabnet_towers_fwd_train(const void* netp, float* params, const float* x1, c
     const float* xs[2] = {x1, x2};
     float* th[2] = {theta1, theta2};
     float* ws[2] = {static_cast<float*>(workspace1), static_cast<float*>(workspace2)};
+    net->stamp(workspace1, 2, workspace2);
+    net->stamp(workspace2, 3, workspace1);
     return run_forward_train(net, params, 2, xs, th, ws, bn_eps, bn_decay, (hipStream_t)stream, static_cast<Prof*>(prof));
 }
 
@@ -1232,10 +1259,26 @@ static int tower_bwd_checks(const Net* net, const float* params, const float* d_
     SN_REQUIRE(workspace_bytes >= stabnet_net_train_workspace_bytes(netp), "tower_bwd: workspace too small");
     return sn_check_device(grads, "tower_bwd: grads", (hipStream_t)stream);
 }
+// The backward must match the forward that filled the workspace (see Net::fwd_stamp).
+static int tower_bwd_pairing(const Net* net, const void* ws1, const void* ws2) {
+    const Net::FwdStamp a = net->stamp_of(ws1);
+    if (ws2 == nullptr) {
+        SN_REQUIRE(a.kind == 1, "tower_bwd: this workspace was last filled by %s; the single-tower backward needs "
+                   "stabnet_tower_fwd_train (the lockstep forward keeps both towers' FC activations in the pair's first workspace: "
+                   "use stabnet_towers_bwd_stage)", a.kind == 0 ? "no training forward of this plan" : "stabnet_towers_fwd_train");
+        return STABNET_OK;
+    }
+    const Net::FwdStamp b = net->stamp_of(ws2);
+    SN_REQUIRE(a.kind == 2 && a.partner == ws2 && b.kind == 3 && b.partner == ws1,
+               "towers_bwd_stage: the two workspaces were not filled together by stabnet_towers_fwd_train(workspace1, workspace2) "
+               "(after two stabnet_tower_fwd_train calls use stabnet_tower_bwd per tower)");
+    return STABNET_OK;
+}
 int stabnet_tower_bwd(const void* netp, const float* params, const float* d_theta, float* grads, void* workspace,
                       size_t workspace_bytes, void* stream, void* prof) {
     const Net* net = static_cast<const Net*>(netp);
     int rc = tower_bwd_checks(net, params, d_theta, grads, workspace, workspace_bytes, netp, stream);
+    if (rc == 0) rc = tower_bwd_pairing(net, workspace, nullptr);
     float* ws[1] = {static_cast<float*>(workspace)};
     for (int stage = 0; rc == 0 && stage < kNumStages; ++stage)
         rc = run_backward_stage(net, params, 1, &d_theta, grads, ws, stage, (hipStream_t)stream, static_cast<Prof*>(prof));
@@ -1247,6 +1290,7 @@ int stabnet_tower_bwd_stage(const void* netp, const float* params, const float* 
                             size_t workspace_bytes, int stage, void* stream, void* prof) {
     const Net* net = static_cast<const Net*>(netp);
     int rc = tower_bwd_checks(net, params, d_theta, grads, workspace, workspace_bytes, netp, stream);
+    if (rc == 0) rc = tower_bwd_pairing(net, workspace, nullptr);
     if (rc) return rc;
     SN_REQUIRE(stage >= 0 && stage < kNumStages, "tower_bwd_stage: stage %d outside [0, %d)", stage, kNumStages);
     float* ws[1] = {static_cast<float*>(workspace)};
@@ -1262,6 +1306,7 @@ int stabnet_towers_bwd_stage(const void* netp, const float* params, const float*
     if (rc) return rc;
     SN_REQUIRE(d_theta2 && workspace2 && workspace2 != workspace1, "towers_bwd_stage: null pointer (or one workspace for both towers)");
     SN_REQUIRE(stage >= 0 && stage < kNumStages, "towers_bwd_stage: stage %d outside [0, %d)", stage, kNumStages);
+    if ((rc = tower_bwd_pairing(net, workspace1, workspace2)) != 0) return rc;
     const float* dt[2] = {d_theta1, d_theta2};
     float* ws[2] = {static_cast<float*>(workspace1), static_cast<float*>(workspace2)};
     return run_backward_stage(net, params, 2, dt, grads, ws, stage, (hipStream_t)stream, static_cast<Prof*>(prof));

@@ -7,7 +7,10 @@
 // All kernels are HBM-bound or tiny.  Every cross-thread reduction is ORDER-INDEPENDENT, so a training step is
 // reproducible bit for bit: sums that many blocks contribute to are accumulated as 64-bit FIXED-POINT integers
 // (integer addition is associative; scale 2^40: resolution 9.1e-13, range +-8.3e6 -- gradients of this objective are
-// 1e-9 .. 1e2), or as block partials reduced in a fixed order by a second small kernel.
+// 1e-9 .. 1e2), or as block partials reduced in a fixed order by a second small kernel.  A contribution that is NaN, Inf or
+// >= 2^22 in magnitude cannot be represented: it sets a POISON word behind the accumulators (atomic OR: still
+// order-independent) and the read-out kernels then emit NaN, so a diverging step shows up as NaN gradients -- as it would
+// with float atomics -- instead of finite garbage that Adam applies.
 #include "common.h"
 #include <algorithm>
 #include <climits>
@@ -17,7 +20,13 @@
 #define SN_FIX_INV (1.0 / 1099511627776.0)
 
 typedef unsigned long long sn_u64;
-__device__ __forceinline__ sn_u64 to_fix(double v) { return (sn_u64)(long long)__double2ll_rn(v * SN_FIX_SCALE); }
+__device__ __forceinline__ sn_u64 to_fix(double v, unsigned* poison) {
+    if (!(fabs(v) < 4194304.0)) {                 // NaN, +-Inf, or outside what the 64-bit accumulator can hold
+        atomicOr(poison, 1u);
+        return 0ull;
+    }
+    return (sn_u64)(long long)__double2ll_rn(v * SN_FIX_SCALE);
+}
 __device__ __forceinline__ double from_fix(sn_u64 v) { return (double)(long long)v * SN_FIX_INV; }
 
 __device__ __forceinline__ float wshfl_b(float v, int src) { return __shfl(v, src, 64); }
@@ -43,6 +52,7 @@ __global__ __launch_bounds__(256) void warp_bwd_pixels_kernel(const float* __res
     for (int i = threadIdx.x; i < cells * 8; i += 256) sAcc[i] = 0ull;
     __syncthreads();
     const float mscale = (dmap_scale != nullptr) ? dmap_scale[n] : 1.0f;   // d_xmap / d_ymap hold counts: gradient = count * scale[n]
+    unsigned* poison = reinterpret_cast<unsigned*>(dHs + (size_t)gridDim.z * cells * 8);     // the word behind the accumulators
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int y = blockIdx.y * 4 + wv;
@@ -98,7 +108,7 @@ __global__ __launch_bounds__(256) void warp_bwd_pixels_kernel(const float* __res
             for (int k = 0; k < 8; ++k) acc[k] += c[k];
         } else {                                           // 4-pixel group straddles a cell seam (rare)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) atomicAdd(&sAcc[cell * 8 + k], to_fix((double)c[k]));
+            for (int k = 0; k < 8; ++k) atomicAdd(&sAcc[cell * 8 + k], to_fix((double)c[k], poison));
         }
     }
     // wave reduction when the whole wave sits in one cell (the common case), LDS atomics otherwise
@@ -110,11 +120,11 @@ __global__ __launch_bounds__(256) void warp_bwd_pixels_kernel(const float* __res
         for (int k = 0; k < 8; ++k) {
             double v = (double)acc[k];
             for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0) atomicAdd(&sAcc[first * 8 + k], to_fix(v));       // (the butterfly order is fixed)
+            if (lane == 0) atomicAdd(&sAcc[first * 8 + k], to_fix(v, poison));       // (the butterfly order is fixed)
         }
     } else if (my_cell >= 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(&sAcc[my_cell * 8 + k], to_fix((double)acc[k]));
+        for (int k = 0; k < 8; ++k) atomicAdd(&sAcc[my_cell * 8 + k], to_fix((double)acc[k], poison));
     }
     __syncthreads();
     for (int i = threadIdx.x; i < cells * 8; i += 256) {
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(1024) void warp_bwd_mesh_kernel(const float* __rest
     double lam = 0.0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) lam += wshfl_d(x, k * 8 + c) * from_fix(g[k]);     // valid in every lane with column c
+    if (*reinterpret_cast<const unsigned*>(dHs + (size_t)N * cells * 8) != 0u) lam = __builtin_nan("");   // poisoned sums (see to_fix)
     const float* h = Hs + ((size_t)n * cells + cell) * 9;
     const double h6 = (double)h[6], h7 = (double)h[7];
     if (r == 0) {                                        // lanes 0..7: c = index j of lambda
@@ -245,6 +256,7 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict
     if (y >= H) return;
     const size_t rowoff = ((size_t)n * H + y) * W;
     sn_u64* dimg = acc_fix + (size_t)n * H * W * C;
+    unsigned* poison = reinterpret_cast<unsigned*>(acc_fix + (size_t)gridDim.z * H * W * C);   // the word behind the accumulators
     for (int e = 0; e < 4 && xb + e < W; ++e) {
         const float xm = xs[rowoff + xb + e], ym = ys[rowoff + xb + e];
         const float xp = (xm + 1.0f) * (float)W / 2.0f, yp = (ym + 1.0f) * (float)H / 2.0f;
@@ -257,11 +269,11 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict
         const float wc = (xp - x0f) * (y1f - yp), wd = (xp - x0f) * (yp - y0f);
         for (int ch = 0; ch < C; ++ch) {
             const float g = d_out[(rowoff + xb + e) * C + ch];
-            if (g == 0.f) continue;
-            atomicAdd(&dimg[((size_t)y0 * W + x0) * C + ch], to_fix((double)(wa * g)));
-            atomicAdd(&dimg[((size_t)y1 * W + x0) * C + ch], to_fix((double)(wb * g)));
-            atomicAdd(&dimg[((size_t)y0 * W + x1) * C + ch], to_fix((double)(wc * g)));
-            atomicAdd(&dimg[((size_t)y1 * W + x1) * C + ch], to_fix((double)(wd * g)));
+            if (g == 0.f) continue;                          // (NaN != 0: a NaN gradient goes on and poisons the sums)
+            atomicAdd(&dimg[((size_t)y0 * W + x0) * C + ch], to_fix((double)(wa * g), poison));
+            atomicAdd(&dimg[((size_t)y1 * W + x0) * C + ch], to_fix((double)(wb * g), poison));
+            atomicAdd(&dimg[((size_t)y0 * W + x1) * C + ch], to_fix((double)(wc * g), poison));
+            atomicAdd(&dimg[((size_t)y1 * W + x1) * C + ch], to_fix((double)(wd * g), poison));
         }
     }
 }
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(256) void fix_to_float_kernel(const sn_u64* __restr
                                                            int accumulate) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float v = (float)from_fix(acc_fix[i]);
+    const float v = (*reinterpret_cast<const unsigned*>(acc_fix + n) != 0u) ? __builtin_nanf("") : (float)from_fix(acc_fix[i]);
     out[i] = accumulate ? out[i] + v : v;
 }
 
@@ -504,7 +516,7 @@ int stabnet_transformer_bwd(const float* pts2, const float* Hs, const float* U, 
     const int cells = grid_h * grid_w;
     SN_REQUIRE(((uintptr_t)workspace & 7) == 0, "transformer_bwd: workspace must be 8-byte aligned");
     sn_u64* dHs = static_cast<sn_u64*>(workspace);
-    if (hipMemsetAsync(workspace, 0, sizeof(sn_u64) * N * cells * 8, st) != hipSuccess) {
+    if (hipMemsetAsync(workspace, 0, sizeof(sn_u64) * ((size_t)N * cells * 8 + 1), st) != hipSuccess) {      // + the poison word
         stabnet_set_error("transformer_bwd: memset failed");
         return STABNET_ERR_LAUNCH;
     }
@@ -518,7 +530,7 @@ int stabnet_transformer_bwd(const float* pts2, const float* Hs, const float* U, 
 }
 
 /* interpolate(im, x, y) backward wrt im (train_bundle_nobm.py:117: the gradient that reaches tower 2's output).
- * workspace: N*H*W*C 8-byte words (fixed-point accumulators), 8-B aligned. */
+ * workspace: N*H*W*C + 1 8-byte words (fixed-point accumulators + the poison word), 8-B aligned. */
 int stabnet_interp_bwd(const float* x, const float* y, const float* d_out, int N, int H, int W, int C, float* d_im,
                        int accumulate, void* workspace, void* stream) {
     SN_REQUIRE(x && y && d_out && d_im && workspace, "interp_bwd: null pointer");
@@ -526,7 +538,7 @@ int stabnet_interp_bwd(const float* x, const float* y, const float* d_out, int N
     SN_REQUIRE(((uintptr_t)workspace & 7) == 0, "interp_bwd: workspace must be 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)N * H * W * C;
-    if (hipMemsetAsync(workspace, 0, sizeof(sn_u64) * (size_t)total, st) != hipSuccess) {
+    if (hipMemsetAsync(workspace, 0, sizeof(sn_u64) * ((size_t)total + 1), st) != hipSuccess) {               // + the poison word
         stabnet_set_error("interp_bwd: memset failed");
         return STABNET_ERR_LAUNCH;
     }

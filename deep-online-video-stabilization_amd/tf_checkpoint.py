@@ -1,4 +1,5 @@
-"""TensorFlow checkpoint (V2 "tensor bundle") reader / writer without TensorFlow (first half).
+"""TensorFlow checkpoint reader / writer without TensorFlow (first half): V2 "tensor bundle" and the older
+V1 single-file format.
 
 The reference restores `models/v2_93/model-80000` through `tf.train.Saver` (deploy_bundle.py:45-47) and initialises training
 from `data_video/resnet_v2_50.ckpt` (train_bundle_nobm.py:184-191).  Neither TF nor any checkpoint exists in the build image, so
@@ -11,8 +12,17 @@ this module restates the PUBLISHED on-disk format from its specification and is 
                                  BundleEntryProto {1: dtype, 2: TensorShapeProto, 3: shard_id, 4: offset, 5: size, 6: crc32c}
   <prefix>.data-00000-of-00001   raw little-endian tensor bytes at [offset, offset + size)
 
-Only what the path needs is supported: uncompressed blocks (BundleWriter writes them uncompressed), one shard or several,
-no sliced (partitioned) variables; dtypes float32/float64/int32/int64.  Anything else raises with a clear message.
+  V1 `<prefix>` (one file; the format slim distributes the ImageNet `resnet_v2_50.ckpt` in -- the checkpoint the reference
+                                 REQUIRES for its warm start, train_bundle_nobm.py:184-191,208): the same leveldb-format table
+                                 (tensorflow/core/util/tensor_slice_writer.cc).  Key "" -> SavedTensorSlices{1: meta =
+                                 SavedTensorSliceMeta{1: repeated SavedSliceMeta{1: name, 2: shape, 3: dtype, 4: slices}}};
+                                 every other key -> SavedTensorSlices{2: data = SavedSlice{1: name, 2: TensorSliceProto,
+                                 3: TensorProto}} with the values in the TYPED repeated field of the TensorProto (float_val = 5,
+                                 double_val = 6, int_val = 7, int64_val = 10; packed or not) or in tensor_content = 4.
+
+Only what the path needs is supported: table blocks uncompressed or Snappy, one shard or several, dtypes
+float32/float64/int32/int64; V2: no sliced (partitioned) variables; V1: slices are assembled into the full tensor.
+Anything else raises with a clear message.
 """
 from __future__ import annotations
 
@@ -105,11 +115,47 @@ def _mask_crc(c):                       # leveldb / TF crc32c::Mask
 
 
 # ------------------------------------------------------------------------------------------------ table reader
+def _snappy_decompress(src: bytes) -> bytes:
+    """Raw Snappy block format (format_description.txt): varint uncompressed length, then literal / copy elements."""
+    n, pos = _get_varint(src, 0)
+    out = bytearray()
+    while pos < len(src):
+        tag = src[pos]; pos += 1
+        kind = tag & 3
+        if kind == 0:                                            # literal
+            ln = tag >> 2
+            if ln >= 60:
+                nb = ln - 59
+                ln = int.from_bytes(src[pos:pos + nb], "little"); pos += nb
+            ln += 1
+            out += src[pos:pos + ln]; pos += ln
+            continue
+        if kind == 1:
+            ln = ((tag >> 2) & 7) + 4
+            off = ((tag >> 5) << 8) | src[pos]; pos += 1
+        elif kind == 2:
+            ln = (tag >> 2) + 1
+            off = src[pos] | (src[pos + 1] << 8); pos += 2
+        else:
+            ln = (tag >> 2) + 1
+            off = int.from_bytes(src[pos:pos + 4], "little"); pos += 4
+        if off == 0 or off > len(out):
+            raise ValueError("tf_checkpoint: corrupt Snappy block")
+        for _ in range(ln):                                      # copies may overlap their own output
+            out.append(out[-off])
+    if len(out) != n:
+        raise ValueError("tf_checkpoint: Snappy block length mismatch")
+    return bytes(out)
+
+
 def _read_block(buf, offset, size):
     ctype = buf[offset + size]
-    if ctype != 0:
-        raise ValueError("tf_checkpoint: compressed table block (type %d); only uncompressed bundles are supported" % ctype)
-    blk = buf[offset:offset + size]
+    if ctype == 1:
+        blk = _snappy_decompress(bytes(buf[offset:offset + size]))
+    elif ctype == 0:
+        blk = buf[offset:offset + size]
+    else:
+        raise ValueError("tf_checkpoint: table block with unknown compression type %d" % ctype)
     nrestart = struct.unpack_from("<I", blk, len(blk) - 4)[0]
     end = len(blk) - 4 - 4 * nrestart
     pos, key, out = 0, b"", []
@@ -176,6 +222,154 @@ def read_bundle(prefix: str, verify_crc_below: int = 1 << 20) -> dict:
         arr = np.frombuffer(bytes(raw), dtype=_DTYPES[dt])
         out[key.decode()] = arr.reshape(dims) if dims else arr.reshape(())
     return out
+
+
+# ------------------------------------------------------------------------------------------------ V1 (single file)
+_V1_VALUE_FIELD = {1: (5, "<f4"), 2: (6, "<f8"), 3: (7, None), 9: (10, None)}      # dtype id -> (TensorProto field, fixed layout or varints)
+
+
+def _tensor_proto_values(tp: dict, dt: int, name: str) -> np.ndarray:
+    """The flat values of a TensorProto as TensorSliceWriter fills it: tensor_content, or the typed repeated field (packed:
+    one length-delimited run; unpacked: one fixed32/64 or varint per element)."""
+    np_dt = _DTYPES[dt]
+    if 4 in tp and tp[4][0]:
+        return np.frombuffer(tp[4][0], dtype=np.dtype(np_dt).newbyteorder("<")).astype(np_dt)
+    field, layout = _V1_VALUE_FIELD[dt]
+    vals = tp.get(field, [])
+    if not vals:
+        return np.zeros(0, np_dt)
+    if isinstance(vals[0], (bytes, bytearray)):                  # packed
+        raw = b"".join(vals)
+        if layout is not None:
+            return np.frombuffer(raw, dtype=layout).astype(np_dt)
+        out, pos = [], 0
+        while pos < len(raw):
+            v, pos = _get_varint(raw, pos)
+            out.append(_signed64(v))
+        return np.asarray(out, np_dt)
+    if layout == "<f4":                                          # unpacked fixed32 came back as ints
+        return np.asarray(vals, np.uint32).view(np.float32).astype(np_dt)
+    if layout == "<f8":
+        return np.asarray(vals, np.uint64).view(np.float64).astype(np_dt)
+    return np.asarray([_signed64(v) for v in vals], np_dt)
+
+
+def _shape_of(shape_proto: bytes):
+    return [_signed64(_parse_proto(d).get(1, [0])[0]) for d in _parse_proto(shape_proto).get(2, [])]
+
+
+def read_v1(path: str) -> dict:
+    """All variables of a V1 checkpoint file as {name: ndarray} (slices of partitioned variables assembled)."""
+    entries = _read_table(path)
+    if not entries or entries[0][0] != b"":
+        raise ValueError("tf_checkpoint: %s has no SavedTensorSlices meta entry (not a V1 checkpoint)" % path)
+    meta = _parse_proto(_parse_proto(entries[0][1]).get(1, [b""])[0])
+    shapes, dtypes = {}, {}
+    for t in meta.get(1, []):
+        m = _parse_proto(t)
+        name = m[1][0].decode()
+        dt = m.get(3, [0])[0]
+        if dt not in _DTYPES:
+            raise ValueError("tf_checkpoint: variable %r has unsupported dtype id %d" % (name, dt))
+        shapes[name] = _shape_of(m[2][0]) if 2 in m else []
+        dtypes[name] = dt
+    out, filled = {}, {}
+    for key, val in entries[1:]:
+        top = _parse_proto(val)
+        if 2 not in top:
+            continue
+        sl = _parse_proto(top[2][0])
+        name = sl[1][0].decode()
+        if name not in shapes:
+            raise ValueError("tf_checkpoint: slice of %r without a meta entry" % name)
+        shape, dt = shapes[name], dtypes[name]
+        tp = _parse_proto(sl[3][0]) if 3 in sl else {}
+        vals = _tensor_proto_values(tp, dt, name)
+        # TensorSliceProto: one Extent per dimension; an empty Extent = the whole dimension
+        ext = [_parse_proto(e) for e in _parse_proto(sl[2][0]).get(1, [])] if 2 in sl else []
+        idx = []
+        for d, full in enumerate(shape):
+            e = ext[d] if d < len(ext) else {}
+            start = _signed64(e.get(1, [0])[0])
+            length = _signed64(e[2][0]) if 2 in e else full - start
+            idx.append(slice(start, start + length))
+        if name not in out:
+            out[name] = np.zeros(shape, _DTYPES[dt])
+            filled[name] = 0
+        view_shape = [i.stop - i.start for i in idx]
+        if int(np.prod(view_shape, dtype=np.int64)) != vals.size:
+            raise ValueError("tf_checkpoint: slice of %r holds %d values, its extent %s needs %d" % (name, vals.size, view_shape, int(np.prod(view_shape))))
+        out[name][tuple(idx)] = vals.reshape(view_shape)
+        filled[name] += vals.size
+    for name, shape in shapes.items():
+        if filled.get(name, -1) != int(np.prod(shape, dtype=np.int64)):
+            raise ValueError("tf_checkpoint: variable %r is incomplete (%d of %d values)" % (name, filled.get(name, 0), int(np.prod(shape))))
+    return out
+
+
+def write_v1(path: str, variables: dict, packed: bool = True, slices_of: dict = None):
+    """Writes {name: ndarray} as a V1 checkpoint file (test fixture generator: the same table + SavedTensorSlices layout
+    TensorSliceWriter produces; keys are 0x00 + name + slice text, which sorts like TF's ordered code for one slice per tensor).
+    slices_of: {name: n} splits that variable along axis 0 into n slices (a partitioned variable)."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+
+    def lend(b):
+        return _put_varint(len(b)) + b
+
+    def shape_proto(shape):
+        return b"".join(_field(2, 2, lend(_field(1, 0, _put_varint(int(d))))) for d in shape)
+
+    metas, datas = [], []
+    for name in sorted(variables, key=lambda s: s.encode()):
+        a = np.asarray(variables[name])
+        a = a if a.flags.c_contiguous else a.copy()              # (ascontiguousarray would promote scalars to 1-D)
+        if a.dtype not in _DTYPE_IDS:
+            raise ValueError("tf_checkpoint: dtype %s of %r is not supported" % (a.dtype, name))
+        dt = _DTYPE_IDS[a.dtype]
+        nsl = (slices_of or {}).get(name, 1)
+        bounds = np.linspace(0, a.shape[0] if a.ndim else 1, nsl + 1).astype(int) if nsl > 1 else None
+        slice_protos = []
+        for k in range(nsl):
+            if nsl == 1:
+                part, sp = a, b"".join(_field(1, 2, lend(b"")) for _ in a.shape)
+            else:
+                lo, hi = int(bounds[k]), int(bounds[k + 1])
+                part = a[lo:hi]
+                sp = _field(1, 2, lend(_field(1, 0, _put_varint(lo)) + _field(2, 0, _put_varint(hi - lo))))
+                sp += b"".join(_field(1, 2, lend(b"")) for _ in a.shape[1:])
+            slice_protos.append(sp)
+            field, layout = _V1_VALUE_FIELD[dt]
+            flat = part.ravel()
+            if layout is not None:
+                raw = flat.astype(layout).tobytes()
+                body = _field(field, 2, lend(raw)) if packed else b"".join(
+                    _field(field, 5 if layout == "<f4" else 1, raw[i:i + (4 if layout == "<f4" else 8)])
+                    for i in range(0, len(raw), 4 if layout == "<f4" else 8))
+            else:
+                vs = b"".join(_put_varint(int(v) & ((1 << 64) - 1)) for v in flat)
+                body = _field(field, 2, lend(vs)) if packed else b"".join(_field(field, 0, _put_varint(int(v) & ((1 << 64) - 1))) for v in flat)
+            tp = _field(1, 0, _put_varint(dt)) + _field(2, 2, lend(shape_proto(part.shape))) + body
+            saved = _field(1, 2, lend(name.encode())) + _field(2, 2, lend(sp)) + _field(3, 2, lend(tp))
+            datas.append((b"\x00" + name.encode() + b"\x00\x01" + bytes([k]), _field(2, 2, lend(saved))))
+        m = _field(1, 2, lend(name.encode())) + _field(2, 2, lend(shape_proto(a.shape))) + _field(3, 0, _put_varint(dt))
+        m += b"".join(_field(4, 2, lend(sp)) for sp in slice_protos)
+        metas.append(_field(1, 2, lend(m)))
+    items = [(b"", _field(1, 2, lend(b"".join(metas))))] + sorted(datas)
+    with open(path, "wb") as f:
+        index_items, cur, cur_bytes = [], [], 0
+        for kv in items:
+            cur.append(kv); cur_bytes += len(kv[0]) + len(kv[1]) + 3
+            if cur_bytes >= 4096:
+                off, size = _emit_block(f, _build_block(cur))
+                index_items.append((cur[-1][0], _put_varint(off) + _put_varint(size)))
+                cur, cur_bytes = [], 0
+        if cur:
+            off, size = _emit_block(f, _build_block(cur))
+            index_items.append((cur[-1][0], _put_varint(off) + _put_varint(size)))
+        moff, msize = _emit_block(f, _build_block([]))
+        ioff, isize = _emit_block(f, _build_block(index_items, restart_interval=1))
+        footer = _put_varint(moff) + _put_varint(msize) + _put_varint(ioff) + _put_varint(isize)
+        f.write(footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", _MAGIC))
 
 
 # ------------------------------------------------------------------------------------------------ table writer
@@ -263,7 +457,7 @@ def load_stabnet_variables(prefix: str):
 def checkpoint_format(prefix: str) -> str:
     """'v2' : `<prefix>.index` is a tensor-bundle table (what tf.train.Saver writes since TF 1.0 and what this module reads);
     'v1' : `<prefix>` itself is a table file -- the older single-file format slim distributes `resnet_v2_50.ckpt` in
-           (SavedTensorSlices values; NOT read here);
+           (SavedTensorSlices values; read by read_v1);
     'none': neither exists;  'unknown': a file exists but is not a table."""
     def is_table(path):
         try:
@@ -283,18 +477,25 @@ def checkpoint_format(prefix: str) -> str:
 
 
 def try_load_imagenet_resnet(prefix: str):
-    """-> (variables or None, note).  Never raises for a missing / unsupported file: the training driver then keeps its
-    seeded initialiser and prints the note (train_bundle_nobm.py:184-191 is an optional warm start)."""
+    """-> (variables or None, note).  None when the file is missing or is not a TensorFlow checkpoint; the reference cannot
+    start without this warm start (restorer.restore, train_bundle_nobm.py:208), so the training driver treats None as an error
+    unless --no-imagenet-init is given."""
+    fmt = checkpoint_format(prefix)
+    if fmt in ("v1", "v2"):
+        return load_imagenet_resnet(prefix), "initialised from the %s checkpoint %s" % (fmt.upper(), prefix)
+    if fmt == "unknown":
+        return None, "%s exists but is not a TensorFlow checkpoint table" % prefix
+    return None, "%s not found" % prefix
+
+
+def read_checkpoint(prefix: str) -> dict:
+    """{name: ndarray} of a V2 bundle (`<prefix>.index`) or a V1 single-file checkpoint (`<prefix>`)."""
     fmt = checkpoint_format(prefix)
     if fmt == "v2":
-        return load_imagenet_resnet(prefix), "initialised from the V2 checkpoint %s" % prefix
+        return read_bundle(prefix)
     if fmt == "v1":
-        return None, ("%s is a V1 (single-file) TensorFlow checkpoint, which this build does not read: convert it once with "
-                      "TensorFlow (`tf.train.Saver(write_version=2)`) or to an .npz of TF variable names; continuing from the "
-                      "seeded initialiser" % prefix)
-    if fmt == "unknown":
-        return None, "%s exists but is not a TensorFlow checkpoint table; continuing from the seeded initialiser" % prefix
-    return None, "%s not found; the backbone starts from the seeded initialiser" % prefix
+        return read_v1(prefix)
+    raise FileNotFoundError("tf_checkpoint: no TensorFlow checkpoint at %s (%s)" % (prefix, fmt))
 
 
 def load_imagenet_resnet(prefix: str):
@@ -303,7 +504,7 @@ def load_imagenet_resnet(prefix: str):
     `stable_net/resnet/<name>` is read from the checkpoint's `<name>` (name_in_checkpoint strips the 18-character scope).
     -> {name without scope: array} of the variables to copy over a fresh initialisation."""
     out = {}
-    for k, v in read_bundle(prefix).items():
+    for k, v in read_checkpoint(prefix).items():
         if not k.startswith("resnet_v2_50/") or k.startswith("resnet_v2_50/conv1/") or "logits" in k:
             continue
         if "Adam" in k or k.endswith("/Momentum"):

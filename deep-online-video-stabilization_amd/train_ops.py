@@ -13,7 +13,7 @@ def transformer_bwd(pts2, Hs, U, x_map, y_map, d_out=None, d_xmap=None, d_ymap=N
     U = dev_f32(U, "U")
     N, H, W, C = U.shape
     d_pts2 = empty((N, cfg.grid_h + 1, cfg.grid_w + 1, 2), U)
-    ws = empty((N * cfg.grid_h * cfg.grid_w * 8,), U, dtype=torch.int64)
+    ws = empty((N * cfg.grid_h * cfg.grid_w * 8 + 1,), U, dtype=torch.int64)    # fixed-point sums + the poison word
     _lib.call("stabnet_transformer_bwd", ptr(dev_f32(pts2)), ptr(dev_f32(Hs)), ptr(U), ptr(dev_f32(x_map)),
               ptr(dev_f32(y_map)), ptr(d_out), ptr(d_xmap), ptr(d_ymap), ptr(dmap_scale), N, H, W, C, cfg.grid_h, cfg.grid_w, ptr(d_pts2),
               ptr(ws), stream_ptr(U.device), device=U.device)
@@ -27,7 +27,7 @@ def interp_bwd(x, y, d_out, d_im=None):
     acc = d_im is not None
     if d_im is None:
         d_im = empty((N, H, W, C), d_out)
-    ws = empty((N * H * W * C,), d_out, dtype=torch.int64)           # fixed-point accumulators of the scatter
+    ws = empty((N * H * W * C + 1,), d_out, dtype=torch.int64)       # fixed-point accumulators of the scatter + the poison word
     _lib.call("stabnet_interp_bwd", ptr(dev_f32(x)), ptr(dev_f32(y)), ptr(d_out), N, H, W, C, ptr(d_im), int(acc), ptr(ws),
               stream_ptr(d_out.device), device=d_out.device)
     return d_im

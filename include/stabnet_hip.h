@@ -181,13 +181,14 @@ int stabnet_probe_hbm_copy(const float* src, float* dst, long n_floats, void* st
  *
  * d transformer / d pts2 (pre-clip vertex gradient) [N,gh+1,gw+1,2] from d_out [N,H,W,C], d_xmap, d_ymap [N,H,W]
  * (each may be NULL); dmap_scale [N] (optional) multiplies d_xmap / d_ymap per sample (stabnet_feature_loss hands over
- * signed counts and that factor).  x_map, y_map, Hs: the forward's outputs.  workspace: N*gh*gw*8 8-byte words (8-B aligned). */
+ * signed counts and that factor).  x_map, y_map, Hs: the forward's outputs.  workspace: N*gh*gw*8 + 1 8-byte words (8-B aligned).
+ * A non-finite or out-of-range (|v| >= 2^22) contribution poisons the sums: the gradients then come out NaN, not finite garbage. */
 int stabnet_transformer_bwd(const float* pts2, const float* Hs, const float* U, const float* x_map, const float* y_map,
                             const float* d_out, const float* d_xmap, const float* d_ymap, const float* dmap_scale, int N,
                             int H, int W, int C, int grid_h, int grid_w, float* d_pts2, void* workspace, void* stream);
 
 /* d interpolate(im, x, y) / d im  (train_bundle_nobm.py:117-118): scatter-add of the four taps, d_im (+)= it.
- * workspace: N*H*W*C 8-byte words (8-B aligned). */
+ * workspace: N*H*W*C + 1 8-byte words (8-B aligned); non-finite contributions give NaN (see stabnet_transformer_bwd). */
 int stabnet_interp_bwd(const float* x, const float* y, const float* d_out, int N, int H, int W, int C, float* d_im,
                        int accumulate, void* workspace, void* stream);
 
@@ -270,7 +271,11 @@ int stabnet_tower_bwd(const void* net, const float* params, const float* d_theta
 int stabnet_tower_bwd_stage(const void* net, const float* params, const float* d_theta, float* grads, void* workspace,
                             size_t workspace_bytes, int stage, void* stream, void* prof);
 /* One backward stage of BOTH towers in lockstep (after stabnet_towers_fwd_train): the bucket of stage k then holds the sum of
- * both towers' gradients.  The dgrad weights are re-packed once, the wgrad slabs of both towers are reduced together. */
+ * both towers' gradients.  The dgrad weights are re-packed once, the wgrad slabs of both towers are reduced together.
+ * PAIRING (checked, STABNET_ERR_BAD_ARG otherwise): the lockstep forward keeps the FC-head activations of both towers in
+ * workspace1, the single-tower forward in its own workspace, so stabnet_towers_bwd_stage(ws1, ws2) must follow
+ * stabnet_towers_fwd_train(ws1, ws2) on the same two workspaces, and stabnet_tower_bwd / _bwd_stage(ws) must follow
+ * stabnet_tower_fwd_train(ws). */
 int stabnet_towers_bwd_stage(const void* net, const float* params, const float* d_theta1, const float* d_theta2, float* grads,
                              void* workspace1, void* workspace2, size_t workspace_bytes, int stage, void* stream, void* prof);
 int stabnet_net_num_grad_stages(void);

@@ -91,12 +91,18 @@ def test_cli_drivers_run(cuda, tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     assert "ignored" in out.stdout and os.path.exists(tmp_path / "output" / "synthetic_stable.npy")
     assert np.load(tmp_path / "output" / "synthetic_stable.npy").shape == (4, 64, 96)
+    # like the reference (restorer.restore, train_bundle_nobm.py:208) the driver refuses to start without the ImageNet backbone ...
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "train_bundle_nobm.py"), "--iters", "1", "--batch-size", "2",
+                          "--height", "64", "--width", "96", "--model-dir", str(tmp_path / "m0"),
+                          "--imagenet-ckpt", str(tmp_path / "absent.ckpt")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode != 0 and "--no-imagenet-init" in out.stderr
+    # ... unless told to train from the seeded initialiser
     out = subprocess.run([sys.executable, os.path.join(ROOT, "train_bundle_nobm.py"), "--iters", "3", "--batch-size", "2",
-                          "--height", "64", "--width", "96", "--model-dir", str(tmp_path / "m"), "--disp-freq", "1"],
-                         env=env, capture_output=True, text=True, timeout=900)
+                          "--height", "64", "--width", "96", "--model-dir", str(tmp_path / "m"), "--disp-freq", "1",
+                          "--no-imagenet-init"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "final loss" in out.stdout and os.path.exists(tmp_path / "m" / "model-2.npz")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "train_bundle_nobm.py"), "--restore", "--iters", "4",
-                          "--batch-size", "2", "--height", "64", "--width", "96", "--model-dir", str(tmp_path / "m")],
-                         env=env, capture_output=True, text=True, timeout=900)
+                          "--batch-size", "2", "--height", "64", "--width", "96", "--model-dir", str(tmp_path / "m"),
+                          "--no-imagenet-init"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "restoring" in out.stdout, out.stderr[-2000:]

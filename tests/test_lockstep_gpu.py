@@ -74,3 +74,44 @@ def test_lockstep_towers_match_tower_after_tower(cuda, N, H, W):
         assert e < 1e-1, (name, e)
     cos = float(np.dot(g_l, g_s) / (np.linalg.norm(g_l) * np.linalg.norm(g_s)))
     assert cos > 1 - 2e-4, cos
+
+
+def test_backward_must_match_the_forward_that_filled_the_workspace(cuda):
+    """The lockstep forward keeps both towers' FC activations in the pair's first workspace, the single-tower forward in its
+    own: a backward of the other kind would read rows that were never written.  The library refuses it (host-side stamp per
+    workspace) instead of returning a silently wrong gradient."""
+    from stabnet_amd import _lib, synthetic
+    from stabnet_amd._tensor import ptr, stream_ptr
+    from stabnet_amd.config import Config
+    from stabnet_amd.regressor import NetPlan
+    N, H, W = 2, 64, 96
+    cfg = Config(height=H, width=W, batch_size=N)
+    plan = NetPlan(N, H, W, cfg, keep_activations=True)
+    params = torch.from_numpy(plan.pack(synthetic.make_params(cfg, seed=0, theta_scale=0.3))).to(cuda)
+    rng = np.random.default_rng(3)
+    xs = [torch.from_numpy(rng.uniform(-0.5, 0.5, (N, H, W, cfg.in_ch)).astype(np.float32)).to(cuda) for _ in range(2)]
+    dth = [torch.from_numpy(rng.standard_normal((N, cfg.n_theta)).astype(np.float32)).to(cuda) for _ in range(2)]
+    nb = _lib.lib().stabnet_net_train_workspace_bytes(plan.handle)
+    ws = [torch.zeros(nb, dtype=torch.uint8, device=cuda) for _ in range(2)]
+    th = [torch.empty((N, cfg.n_theta), dtype=torch.float32, device=cuda) for _ in range(2)]
+    grads = torch.zeros(plan.n_trainable, dtype=torch.float32, device=cuda)
+    st = stream_ptr(cuda)
+    with pytest.raises(_lib.StabnetError, match="no training forward"):
+        _lib.call("stabnet_tower_bwd", plan.handle, ptr(params), ptr(dth[0]), ptr(grads), ptr(ws[0]), nb, st, 0, device=cuda)
+    _lib.call("stabnet_towers_fwd_train", plan.handle, ptr(params), ptr(xs[0]), ptr(xs[1]), ptr(th[0]), ptr(th[1]), ptr(ws[0]), ptr(ws[1]),
+              nb, cfg.bn_eps, cfg.bn_decay, st, 0, device=cuda)
+    with pytest.raises(_lib.StabnetError, match="stabnet_towers_bwd_stage"):
+        _lib.call("stabnet_tower_bwd", plan.handle, ptr(params), ptr(dth[0]), ptr(grads), ptr(ws[0]), nb, st, 0, device=cuda)
+    with pytest.raises(_lib.StabnetError, match="not filled together"):           # the pair in the wrong order
+        _lib.call("stabnet_towers_bwd_stage", plan.handle, ptr(params), ptr(dth[0]), ptr(dth[1]), ptr(grads), ptr(ws[1]), ptr(ws[0]), nb, 0,
+                  st, 0, device=cuda)
+    _lib.call("stabnet_towers_bwd_stage", plan.handle, ptr(params), ptr(dth[0]), ptr(dth[1]), ptr(grads), ptr(ws[0]), ptr(ws[1]), nb, 0, st, 0,
+              device=cuda)
+    for t in (0, 1):
+        _lib.call("stabnet_tower_fwd_train", plan.handle, ptr(params), ptr(xs[t]), ptr(th[t]), ptr(ws[t]), nb, cfg.bn_eps, cfg.bn_decay, st, 0,
+                  device=cuda)
+    with pytest.raises(_lib.StabnetError, match="not filled together"):
+        _lib.call("stabnet_towers_bwd_stage", plan.handle, ptr(params), ptr(dth[0]), ptr(dth[1]), ptr(grads), ptr(ws[0]), ptr(ws[1]), nb, 0,
+                  st, 0, device=cuda)
+    _lib.call("stabnet_tower_bwd", plan.handle, ptr(params), ptr(dth[0]), ptr(grads), ptr(ws[0]), nb, st, 0, device=cuda)
+    torch.cuda.synchronize()

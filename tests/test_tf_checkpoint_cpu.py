@@ -72,8 +72,9 @@ def test_checkpoint_feeds_the_plan_layout(tmp_path):
 
 
 def test_imagenet_init_formats(tmp_path):
-    """The reference warm-starts from `data_video/resnet_v2_50.ckpt` (train_bundle_nobm.py:184), which slim ships as a V1
-    single-file checkpoint: a bare table file without `.index`.  That must not crash the training driver."""
+    """The reference warm-starts from `data_video/resnet_v2_50.ckpt` (train_bundle_nobm.py:184,208), which slim ships as a V1
+    single-file checkpoint: a bare table file without `.index`.  Both formats initialise the backbone; conv1 (13 input channels
+    instead of 3) and the classifier are excluded."""
     rng = np.random.default_rng(1)
     var = {"resnet_v2_50/block1/unit_1/bottleneck_v2/conv1/weights": rng.standard_normal((1, 1, 64, 64)).astype(np.float32),
            "resnet_v2_50/conv1/weights": rng.standard_normal((7, 7, 3, 64)).astype(np.float32),
@@ -84,15 +85,38 @@ def test_imagenet_init_formats(tmp_path):
     assert C.checkpoint_format(v2) == "v2"
     got, note = C.try_load_imagenet_resnet(v2)
     assert set(got) == {"resnet_v2_50/block1/unit_1/bottleneck_v2/conv1/weights"} and "V2" in note   # conv1 + logits excluded
-    # a V1 file = the table itself under the bare name (same leveldb table magic, no .index / .data shards)
     v1 = str(tmp_path / "v1" / "resnet_v2_50.ckpt")
-    os.makedirs(os.path.dirname(v1))
-    os.replace(v2 + ".index", v1)
+    C.write_v1(v1, var)
     assert C.checkpoint_format(v1) == "v1"
-    got, note = C.try_load_imagenet_resnet(v1)
-    assert got is None and "V1" in note and "seeded" in note
+    got1, note = C.try_load_imagenet_resnet(v1)
+    assert set(got1) == set(got) and "V1" in note
+    assert all(np.array_equal(got1[k], var[k]) for k in got1)
     junk = str(tmp_path / "junk.ckpt")
     open(junk, "wb").write(b"not a checkpoint" * 10)
     assert C.checkpoint_format(junk) == "unknown" and C.try_load_imagenet_resnet(junk)[0] is None
     assert C.checkpoint_format(str(tmp_path / "absent")) == "none"
     assert "not found" in C.try_load_imagenet_resnet(str(tmp_path / "absent"))[1]
+
+
+def test_v1_checkpoint_layouts(tmp_path):
+    """V1 single-file checkpoints (tensor_slice_writer.cc): values in the TensorProto's typed repeated field, packed (what
+    proto3 writes) or one element per tag, all four dtypes, scalars, a partitioned variable assembled from its slices, and
+    Snappy-compressed table blocks."""
+    rng = np.random.default_rng(2)
+    var = {"a/weights": rng.standard_normal((3, 3, 5, 7)).astype(np.float32), "a/step": np.array(12345678901, np.int64),
+           "a/d": rng.standard_normal((4, 2)), "a/i": rng.integers(-1000, 1000, (9,), dtype=np.int32),
+           "part/w": rng.standard_normal((10, 6)).astype(np.float32), "z/empty_dim": np.zeros((0, 4), np.float32)}
+    for packed in (True, False):
+        path = str(tmp_path / ("v1_%d.ckpt" % packed))
+        C.write_v1(path, var, packed=packed, slices_of={"part/w": 3})
+        got = C.read_v1(path)
+        assert set(got) == set(var)
+        for k in var:
+            assert got[k].dtype == var[k].dtype and got[k].shape == var[k].shape and np.array_equal(got[k], var[k]), k
+        assert C.read_checkpoint(path).keys() == got.keys()
+    # the Snappy block decoder (format_description.txt): one literal; literal + overlapping copy; a copy from before the start
+    assert C._snappy_decompress(bytes([11, 0x28]) + b"ab" + b"cdefghi" + b"jk") == b"abcdefghijk"[:11]
+    # Snappy: literal "abcd" + copy(offset 4, length 8) -> "abcdabcdabcd"
+    assert C._snappy_decompress(bytes([12, (4 - 1) << 2]) + b"abcd" + bytes([((8 - 4) << 2) | 1, 4])) == b"abcdabcdabcd"
+    with pytest.raises(ValueError):
+        C._snappy_decompress(bytes([4, 0x01 | (0 << 2), 9]))                 # copy from before the start

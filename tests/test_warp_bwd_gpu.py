@@ -112,3 +112,36 @@ def test_masked_mse_and_feature_loss(cuda):
     assert rel(gx, ft.grad.numpy()[..., 0]) < 1e-5 and rel(gy, ft.grad.numpy()[..., 1]) < 1e-5
     want_warped, _ = O.warp_pts(matches[:, :, :2], flow, cfg)
     assert np.array_equal(warped.cpu().numpy(), want_warped)
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), 1e9])
+def test_non_finite_gradients_propagate_through_the_fixed_point_sums(cuda, bad):
+    """The order-independent 64-bit fixed-point accumulators cannot hold NaN / Inf / |v| >= 2^22: such a contribution poisons
+    the sums and the gradients come out NaN (a diverging step must not hand Adam finite-looking garbage), while a clean call on
+    the same buffers afterwards is finite again."""
+    from stabnet_amd import train_ops, warp
+    from stabnet_amd.config import Config
+    N, H, W = 2, 32, 64
+    cfg = Config(height=H, width=W, batch_size=N)
+    rng = np.random.default_rng(0)
+    dev = lambda a: torch.from_numpy(a).to(cuda)
+    theta = dev((rng.standard_normal((N, 50)) * 0.05).astype(np.float32))
+    U = dev((rng.random((N, H, W, 1)) - 0.5).astype(np.float32))
+    r = warp.warp_from_theta(U, theta, cfg)
+    g = rng.standard_normal((N, H, W, 1)).astype(np.float32)
+    clean = train_ops.transformer_bwd(r["pts2"], r["Hs"], U, r["x_map"], r["y_map"], dev(g), None, None, cfg)
+    assert torch.isfinite(clean).all()
+    gb = g.copy()
+    gb[1, 7, 9, 0] = bad
+    d_pts2 = train_ops.transformer_bwd(r["pts2"], r["Hs"], U, r["x_map"], r["y_map"], dev(gb), None, None, cfg)
+    assert torch.isnan(d_pts2).any(), "a %r in d_out left a finite d_pts2" % bad
+    again = train_ops.transformer_bwd(r["pts2"], r["Hs"], U, r["x_map"], r["y_map"], dev(g), None, None, cfg)
+    assert torch.equal(again, clean)
+    # the flow sampler's scatter: d_im
+    fx = dev(rng.uniform(-1, 1, (N, H, W)).astype(np.float32))
+    fy = dev(rng.uniform(-1, 1, (N, H, W)).astype(np.float32))
+    d_clean = train_ops.interp_bwd(fx, fy, dev(g))
+    assert torch.isfinite(d_clean).all()
+    d_im = train_ops.interp_bwd(fx, fy, dev(gb))
+    assert torch.isnan(d_im).any(), "a %r in d_out left a finite d_im" % bad
+    assert torch.equal(train_ops.interp_bwd(fx, fy, dev(g)), d_clean)

@@ -33,8 +33,11 @@ def build_parser():
     p.add_argument('--model-dir', default=None)
     p.add_argument('--disp-freq', type=int, default=None)
     p.add_argument('--imagenet-ckpt', default='data_video/resnet_v2_50.ckpt',
-                   help='TF checkpoint that initialises the backbone except conv1 and the fc head (reference: '
-                        'train_bundle_nobm.py:184-191); skipped with a note when the file is absent')
+                   help='TF checkpoint (V1 single file as slim ships it, or V2) that initialises the backbone except conv1 and '
+                        'the fc head (reference: train_bundle_nobm.py:184-191,208).  Like the reference, training does not start '
+                        'without it -- unless --no-imagenet-init is given')
+    p.add_argument('--no-imagenet-init', action='store_true',
+                   help='start from the seeded initialiser instead of the ImageNet backbone (synthetic runs, benchmarks)')
     p.add_argument('--augment', action='store_true',
                    help='assemble every batch on the device from un-augmented pair material with the reference\'s random '
                         'crop / flip / contrast / brightness / homography masks (get_data_mini_after.py)')
@@ -68,7 +71,14 @@ def main():
     N, H, W = cfg.batch_size, cfg.height, cfg.width
     init = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
     from stabnet_amd import tf_checkpoint
-    pre, note = tf_checkpoint.try_load_imagenet_resnet(args.imagenet_ckpt)       # train_bundle_nobm.py:184-191,208
+    if args.no_imagenet_init:
+        pre, note = None, 'seeded initialiser (--no-imagenet-init)'
+    else:
+        pre, note = tf_checkpoint.try_load_imagenet_resnet(args.imagenet_ckpt)       # train_bundle_nobm.py:184-191,208
+        if pre is None:
+            # the reference's restorer.restore() raises here; silently training from scratch would be a different experiment
+            raise SystemExit('train_bundle_nobm.py: cannot warm-start the backbone: %s.  Provide --imagenet-ckpt <resnet_v2_50.ckpt> '
+                             '(V1 or V2 TensorFlow checkpoint) or pass --no-imagenet-init to train from the seeded initialiser.' % note)
     if pre is not None:
         hit = [k for k in pre if k in init and pre[k].shape == init[k].shape]
         for k in hit:
