@@ -107,8 +107,8 @@ def empirical_peaks(dev):
     return {"mfma_f32_tflops": mfma, "mfma_clock_ghz": clock_ghz,
             "mfma_f32_tflops_at_2p4ghz": mfma * 2.4 / clock_ghz if clock_ghz > 0 else None, "hbm_copy_gbps": hbm,
             "how": "stabnet_probe_mfma_f32 (register-only v_mfma_f32_32x32x2_f32, 2048 WGs; clock = s_memtime / s_memrealtime "
-                   "inside the loop, median over workgroups) / stabnet_probe_hbm_copy (1 GiB float4 copy, 8 loads in flight per "
-                   "lane, read+write bytes)"}
+                   "inside the loop, median over workgroups) / stabnet_probe_hbm_copy (1 GiB float4 copy, one non-temporal "
+                   "float4 per thread, read+write bytes)"}
 
 
 def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
@@ -187,8 +187,9 @@ def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
     return out
 
 
-PMC_FILE = os.path.join("profiles", "r02_pmc_hbm_traffic_bench720p.json")
-PMC_FILE_TRAIN = os.path.join("profiles", "r02_pmc_hbm_traffic_train_b8.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc_hbm_traffic_bench720p.json")
+PMC_FILE_TRAIN = os.path.join("profiles", "r03_pmc_hbm_traffic_train_b8.json")
+PMC_FILE_1080P = os.path.join("profiles", "r03_pmc_hbm_traffic_bench1080p.json")       # BASELINE configs[4] shape on one GPU
 
 
 def pmc_traffic(kernel, workload_is_default, pmc_file=None):
@@ -199,7 +200,7 @@ def pmc_traffic(kernel, workload_is_default, pmc_file=None):
     PMC_FILE = pmc_file or globals()["PMC_FILE"]
     path = os.path.join(ROOT, PMC_FILE)
     if not workload_is_default:
-        return None, "PMC passes exist for the default workloads only (720p batch 1; training 8 pairs at 288x512)"
+        return None, "PMC passes exist for the BASELINE workloads only (720p / 1080p batch 1; training 8 pairs at 288x512)"
     if not os.path.exists(path):
         return None, "no %s (run tools/refresh_profiles.sh on the GPU box)" % PMC_FILE
     try:
@@ -443,14 +444,17 @@ def main():
         torch.cuda.synchronize()
         prof_ms = 1e3 * (time.perf_counter() - t1) / args.steps
         roof, table = roofline_from_records(prof.records(), args.steps)
+        # PMC passes exist for the two BASELINE inference shapes (720p = configs[1], 1080p = the per-GPU shape of configs[4])
+        pmc_file = {(720, 1280): PMC_FILE, (1080, 1920): PMC_FILE_1080P}.get((H, W))
+        pmc_ok = pmc_file is not None and (S, args.refine) == (1, 1)
         for row in table:                      # the HBM-bound kernel of the path: the fused map + gather warp
             if row["kernel"] == "warp_sample_kernel":
                 # sampler + feedback push in one launch: 20 HW (src, out, black, maps) + 12 HW (ring frame, ring mask, frame_fb)
                 roof_warp = {"bound": "hbm", "kernel": "warp_sample_kernel<1>", "achieved": row["gbps"], "peak": PEAK_HBM_GBPS,
                              "unit": "GB/s", "frac": row["gbps"] / PEAK_HBM_GBPS, "avg_launch_us": row["avg_us"],
                              "algorithmic_bytes_per_launch": S * (32.0 * H * W + 776.0),
-                             "traffic": pmc_traffic("warp_sample_kernel<1>", (H, W, S, args.refine) == (720, 1280, 1, 1))[0]}
-        roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], (H, W, S, args.refine) == (720, 1280, 1, 1))
+                             "traffic": pmc_traffic("warp_sample_kernel<1>", pmc_ok, pmc_file)[0]}
+        roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], pmc_ok, pmc_file)
 
     bf16 = None
     if rank == 0 and not args.no_bf16_leg:

@@ -44,6 +44,8 @@ struct Prof;
 // reference is fp32 end to end.  (A launch argument, not a ConvArgs field: the fp32 kernels' argument block -- and with it their
 // register allocation -- stays exactly what it was; an extra field cost the fp32 path 1 %.)
 int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof = nullptr, int bf16_operands = 0);
+// 1 if that launch is followed by a split-K reduce launch (0: no split, or the split runs inside the workgroups)
+int conv_reduce_launches(const ConvArgs& a);
 
 // The two siamese towers of a training step as ONE launch (forward convolutions, conv_kernel.h).  `a` describes the pair as one
 // batch of 2N samples whose first N live where a.x / a.y / a.residual / a.in_scale / a.in_shift point; tiles of rows >= m_tower

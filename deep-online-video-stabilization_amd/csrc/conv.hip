@@ -262,6 +262,54 @@ static int launch_ring(const ConvArgs& a, hipStream_t st) {
     return a.pad == 0 ? launch_ring_mode<0>(a, st) : launch_ring_mode<1>(a, st);
 }
 
+// Split-K inside the workgroup (conv_ring_kernel.h, "KG"): a launch strategy for a given split count, chosen here for the
+// planner (no reduce launch counted) and for the launcher alike.  Ring path only: 3 groups x 48 KiB of ring = one 12-wave workgroup
+// per CU; the slices must be equal (steps % 3 == 0).  Measured at 720p (rocprofv3 inside the graph replay, block-3 conv2, M = 3600,
+// N = 256, K = 2304): 45.3 us against 45.8 us + a 4.9 us reduce launch.  The register-staged kernel's two-group form lost
+// (30.8 vs 24.3 + 4.9 us) and was removed.
+static int conv_kgroups(const ConvArgs& a, bool ring) {
+    static const int on = env_int("STABNET_CONV_KGROUPS", 1);
+    if (!on || a.splitk < 2 || g_bf16_operands) return 1;
+    const int steps = conv_total_steps(a);
+    if (a.steps_per_split * a.splitk != steps) return 1;
+    return (ring && a.splitk == 3 && !a.rowrun) ? 3 : 1;
+}
+
+static int g_cus = 0;
+static int device_cus() {
+    if (g_cus == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return 0;
+        g_cus = cus;
+    }
+    return g_cus;
+}
+
+static int launch_ring_kg3(const ConvArgs& a, hipStream_t st) {
+    const int cus = device_cus();
+    if (cus <= 0) {
+        stabnet_set_error("conv: cannot read the CU count");
+        return STABNET_ERR_LAUNCH;
+    }
+    const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64);
+    const int grid = (int)std::min<long>(ntiles, cus);                 // 144 KiB of LDS: one workgroup per CU
+    if (a.pad == 0) conv_ring_f32_kernel<0, 0, 3><<<grid, 768, 0, st>>>(a);
+    else conv_ring_f32_kernel<1, 0, 3><<<grid, 768, 0, st>>>(a);
+    SN_LAUNCH_CHECK("conv_ring_f32_kernel<KG=3>");
+    return STABNET_OK;
+}
+
+// 1 if conv_launch() of this (planned) convolution is followed by a split-K reduce launch (plan-time view: the prologue is known
+// from in_scale_expected)
+int conv_reduce_launches(const ConvArgs& a) {
+    if (a.splitk < 2) return 0;
+    int splitk_unused = 1;
+    const int t = pick_tile(a, splitk_unused);
+    const bool ring = ring_eligible(a, t, a.in_scale_expected != 0);
+    return (t == T64x64 && conv_kgroups(a, ring) > 1) ? 0 : 1;
+}
+
 int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands) {
     g_bf16_operands = bf16_operands;
     SN_REQUIRE(a.rowrun || a.Cin % 16 == 0, "conv: Cin=%d must be a multiple of 16 (pad the channels)", a.Cin);
@@ -277,7 +325,10 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands
     const bool rec = prof != nullptr && prof->begin(st);
     const bool ring = ring_eligible(a, t);
     SN_REQUIRE(ring || a.x_ld == a.Cin, "conv: a strided input (x_ld %d != Cin %d) needs the ring kernel", a.x_ld, a.Cin);
-    if (ring) {
+    const int kg = (t == T64x64) ? conv_kgroups(a, ring) : 1;
+    if (kg > 1) {
+        rc = launch_ring_kg3(a, st);
+    } else if (ring) {
         rc = launch_ring(a, st);
     } else if (bk32) {
         if (t == T128x128) rc = launch_one<128, 128, 32, 64, 64>(a, st);
@@ -290,7 +341,9 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands
     }
     const int mode = (a.up > 1 || a.rowrun) ? 2 : (a.pad == 0 ? 0 : 1);
     int kind = PK_KERNEL_CONV_RING + mode + (bf16_operands ? 3 : 0);
-    if (!ring) {                                                  // + 18 for the one-stage (NBUF = 1), + 36 for the bf16-operand instantiation
+    if (kg > 1) {
+        kind = PK_KERNEL_CONV_KG + mode;
+    } else if (!ring) {                                                  // + 18 for the one-stage (NBUF = 1), + 36 for the bf16-operand instantiation
         int bm, bn, nbuf, bf16;
         tile_dims(t, bm, bn);
         igemm_variant(a, bm, bn, bk32 ? 32 : 16, mode, nbuf, bf16);
@@ -300,7 +353,7 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands
                        4.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.K * a.Cout + (double)a.M * a.Cout * a.splitk),
                        a.M, a.Cout, a.K, a.splitk);
     if (rc) return rc;
-    if (a.splitk > 1) {
+    if (a.splitk > 1 && kg == 1) {
         const size_t q = (size_t)a.M * (a.Cout / 4);
         const bool rec2 = prof != nullptr && prof->begin(st);
         conv_splitk_reduce_kernel<<<cdiv((long)q, 256), 256, 0, st>>>(a);

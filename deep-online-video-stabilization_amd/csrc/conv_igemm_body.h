@@ -4,6 +4,9 @@
 // readable address -- are in scope there).
 // Text rather than a __device__ function on purpose: moving the body into a function changed the register allocation of the
 // inference instantiations (ISA diff), and those kernels are on the headline path.
+// (Round 3 built this body with the K split INSIDE the workgroup as well -- two groups of 256 threads, LDS reduction, no reduce
+//  launch -- for the block-3 conv1 layers of the 720p frame: 30.8 us against 24.3 + 4.9 us for kernel + reduce launch, rocprofv3
+//  in the graph replay; removed again.  The ring kernel keeps its form of it, conv_ring_kernel.h KG.)
     constexpr int PITCH = BK + 4;
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;

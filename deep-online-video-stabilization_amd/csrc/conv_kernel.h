@@ -63,10 +63,11 @@ constexpr int SN_EPI_WAVE_BYTES = 32 * 32 * 4;
 #define SN_EPI_W(r) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(wr), "v"(a[r]), "n"((((r) & 3) + 8 * ((r) >> 2)) * 128) : "memory")
 #define SN_EPI_R(q, dst) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(rd), "n"((q) * 1024) : "memory")
 
-template <int TM, int TN>
+// NOSPLIT: p.splitk > 1 describes a split INSIDE the workgroup (the accumulators handed in are already the full sum): full epilogue.
+template <int TM, int TN, bool NOSPLIT = false>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& p, int mw0, int nw0, int lane, int z,
                                               unsigned scratch) {
-    const bool split = p.splitk > 1;
+    const bool split = !NOSPLIT && p.splitk > 1;
     float* const outp = split ? p.partial + (size_t)z * p.M * p.Cout : p.y;
     const bool has_res = !split && p.residual != nullptr;
     const bool has_obn = !split && p.out_scale != nullptr;

@@ -19,6 +19,12 @@
 //            first stages of the next tile are in flight while the current tile's epilogue runs.  The epilogue's
 //            transposition scratch overlays the stage that was consumed last (free until the step after next issues
 //            into it, behind a barrier).
+//   KG > 1 : split-K INSIDE the workgroup.  KG groups of 4 waves, each with its own 3-stage ring (KG x 48 KiB of LDS), walk the
+//            same tiles in lockstep (the per-step barrier is workgroup-wide), group g accumulating K slice g (p.splitk == KG,
+//            every slice p.steps_per_split steps).  At a tile's end groups 1.. park their accumulators in the ring slot they
+//            have just retired, one barrier, group 0 adds them in group order and runs the FULL epilogue: no partial slabs in
+//            HBM and no reduce launch (4.6 us + a 12 MB round trip per split-K layer of the 720p frame).  One workgroup per
+//            CU keeps 12 waves resident, as three co-resident split-K workgroups did.
 #pragma once
 #include "conv_kernel.h"
 #include <type_traits>
@@ -48,18 +54,20 @@ typedef __bf16 sn_bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 sn_bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int MODE /* 0: no padding, 1: zero padding, 2: row-run A operand on a zero-BORDERED image (ConvArgs::rowrun) */,
-          int BF16 = 0 /* 1: fragments rounded to bf16 at read time, v_mfma_f32_32x32x16_bf16 (conv_launch's bf16_operands) */>
-__global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
+          int BF16 = 0 /* 1: fragments rounded to bf16 at read time, v_mfma_f32_32x32x16_bf16 (conv_launch's bf16_operands) */,
+          int KG = 1 /* K groups of 4 waves: split-K inside the workgroup (p.splitk == KG), see the header comment */>
+__global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs p) {
     constexpr int BM = 64, BN = 64, BK = 32;
     constexpr int STAGE = (BM + BN) * BK;                  // floats
-    __shared__ __attribute__((aligned(16))) float ring[3 * STAGE];
+    __shared__ __attribute__((aligned(16))) float ring[KG * 3 * STAGE];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (KG > 1) ? ((tid >> 6) & 3) : (tid >> 6);
+    const int grp = (KG > 1) ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;      // K group = K slice of this wave
     SN_STAMP(0); SN_STAMP_RT(4);
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.Cout + BN - 1) / BN;
     const int tiles_mn = tiles_m * tiles_n;
-    const int ntiles = tiles_mn * p.splitk;                // K slice slowest, then M tile, N tile fastest
+    const int ntiles = (KG > 1) ? tiles_mn : tiles_mn * p.splitk;   // K slice slowest, then M tile, N tile fastest (KG > 1: the slice is the group)
     // Tiles of this workgroup: t_first, t_first + t_stride, ... < t_end.  Plain: b, b + G, ...  XCD-aware (xcd_swizzle):
     // the dispatcher deals workgroup ids round-robin over the 8 XCDs (own 4 MiB L2 each), so the workgroups with equal
     // b % 8 share an L2; they take one CONTIGUOUS eighth of the tile list (N tile fastest, then M): that XCD then reads
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     const int run_steps = (MODE == 2) ? p.K / (p.KH * BK) : 0;     // K-steps per filter row (MODE 2)
     const int total_steps = (MODE == 2) ? p.K / BK : p.KH * p.KW * cin_steps;
     const int last_slice_steps = total_steps - (p.splitk - 1) * p.steps_per_split;
-    const unsigned lds_base = (unsigned)(size_t)(sn_lds_ptr_t)ring;
+    const unsigned lds_base = (unsigned)(size_t)(sn_lds_ptr_t)ring + (KG > 1 ? (unsigned)grp * (3u * STAGE * 4u) : 0u);   // this group's ring
 
     // consumer steps of this workgroup (every slice has steps_per_split steps except the last one)
     int remaining = 0;
@@ -98,8 +106,8 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     int l_tap = 0, l_c0 = 0, l_kw = 0;                     // MODE 2: l_tap = filter row kh, l_kw = 32-float step inside its run
     const float *xb = p.x, *wb = p.w;
     auto producer_setup = [&]() {
-        const int z = pt / tiles_mn;
-        const int mn = pt - z * tiles_mn;
+        const int z = (KG > 1) ? grp : pt / tiles_mn;
+        const int mn = (KG > 1) ? pt : pt - z * tiles_mn;
         const int mt = mn / tiles_n, nt = mn - mt * tiles_n;
         const int m0 = mt * BM, n0 = nt * BN;
         const int ks_begin = z * p.steps_per_split;
@@ -230,8 +238,8 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
     // ---- consumer state: the tile being accumulated
     int ct = t_first, c_left = 0, c_m0 = 0, c_n0 = 0, c_z = 0;
     auto consumer_setup = [&]() {
-        c_z = ct / tiles_mn;
-        const int mn = ct - c_z * tiles_mn;
+        c_z = (KG > 1) ? grp : ct / tiles_mn;
+        const int mn = (KG > 1) ? ct : ct - c_z * tiles_mn;
         const int mt = mn / tiles_n;
         c_m0 = mt * BM;
         c_n0 = (mn - mt * tiles_n) * BN;
@@ -394,6 +402,38 @@ __global__ __launch_bounds__(256) void conv_ring_f32_kernel(const ConvArgs p) {
             if (more) SN_WAIT0();                          // the next tile's first fragments: landed before the epilogue code
             else SN_BARRIER();                             // (otherwise the barrier above already retired slot SLOT)
             SN_STAMP(2);
+            if constexpr (KG > 1) {
+                // Slot SLOT of EVERY group is free here (the workgroup-wide barrier above retired it).  Groups 1.. park their
+                // accumulators in their own slot, [wave][q][lane] in 16-B units (conflict-free both ways); one barrier; group 0
+                // adds them in group order -- a fixed order: the result does not depend on timing -- and runs the full epilogue.
+                // Inline asm for the same reason as the fragment reads: a compiler-visible LDS access would drain the DMA queue.
+                const unsigned red = lds_base + (unsigned)(OFF + wave * 4096 + lane * 16);
+                if (grp > 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc[0][0][4 * q], acc[0][0][4 * q + 1], acc[0][0][4 * q + 2], acc[0][0][4 * q + 3]};
+                        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(red), "v"(v), "n"(q * 1024) : "memory");
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                SN_BARRIER();
+                if (grp == 0) {
+#pragma unroll
+                    for (int g = 1; g < KG; ++g) {
+                        f32x4 t0, t1, t2, t3;
+                        const unsigned src = red + (unsigned)(g * 3 * STAGE * 4);
+                        asm volatile("ds_read_b128 %0, %4 offset:0\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                                     "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(src) : "memory");
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[0][0][e] += t0[e]; acc[0][0][4 + e] += t1[e]; acc[0][0][8 + e] += t2[e]; acc[0][0][12 + e] += t3[e];
+                        }
+                    }
+                    conv_epilogue<1, 1, true>(acc, p, c_m0 + wm * 32, c_n0 + wn * 32, lane, 0,
+                                              lds_base + (unsigned)(OFF + wave * SN_EPI_WAVE_BYTES));
+                }
+            } else
             conv_epilogue<1, 1>(acc, p, c_m0 + wm * 32, c_n0 + wn * 32, lane, c_z,
                                 lds_base + (unsigned)(OFF + wave * SN_EPI_WAVE_BYTES));
 #if RING_STAMP

@@ -637,13 +637,15 @@ const char* stabnet_prof_kind_name(int kind) {
                                              "conv_igemm_f32_pair_kernel<64, 64, 16, 32, 32, 1>", "conv_igemm_f32_pair_kernel<64, 64, 32, 32, 32, 1>"};
         return names[kind - PK_KERNEL_CONV_PAIR];
     }
+    if (kind == PK_KERNEL_CONV_KG) return "conv_ring_f32_kernel<0, 0, 3>";
+    if (kind == PK_KERNEL_CONV_KG + 1) return "conv_ring_f32_kernel<1, 0, 3>";
     // names as rocprofv3 prints the template instantiation <MODE, BF16>
-    if (kind == PK_KERNEL_CONV_RING) return "conv_ring_f32_kernel<0, 0>";
-    if (kind == PK_KERNEL_CONV_RING + 1) return "conv_ring_f32_kernel<1, 0>";
-    if (kind == PK_KERNEL_CONV_RING + 2) return "conv_ring_f32_kernel<2, 0>";
-    if (kind == PK_KERNEL_CONV_RING + 3) return "conv_ring_f32_kernel<0, 1>";
-    if (kind == PK_KERNEL_CONV_RING + 4) return "conv_ring_f32_kernel<1, 1>";
-    if (kind == PK_KERNEL_CONV_RING + 5) return "conv_ring_f32_kernel<2, 1>";
+    if (kind == PK_KERNEL_CONV_RING) return "conv_ring_f32_kernel<0, 0, 1>";
+    if (kind == PK_KERNEL_CONV_RING + 1) return "conv_ring_f32_kernel<1, 0, 1>";
+    if (kind == PK_KERNEL_CONV_RING + 2) return "conv_ring_f32_kernel<2, 0, 1>";
+    if (kind == PK_KERNEL_CONV_RING + 3) return "conv_ring_f32_kernel<0, 1, 1>";
+    if (kind == PK_KERNEL_CONV_RING + 4) return "conv_ring_f32_kernel<1, 1, 1>";
+    if (kind == PK_KERNEL_CONV_RING + 5) return "conv_ring_f32_kernel<2, 1, 1>";
     if (kind >= PK_KERNEL_CONV_BASE && kind < PK_KERNEL_CONV_BASE + 72) {
         // names as rocprofv3 prints the template instantiation: <BM, BN, BK, WM, WN, MODE, NBUF, BF16>
         // (kind = base + MODE*6 + tile*2 + (BK==32) + 18 if NBUF == 1 + 36 if BF16, conv.hip)
@@ -715,7 +717,7 @@ int stabnet_net_num_launches(const void* netp) {
     if (!net) return -1;
     int n = 0;
     // (shortened head: GAP partials + fc_1 = 2 launches, fc_2, fc_3, output layer [+ mesh] = 3; else 2 + 4 x fc_launches)
-    for (const Step& s : net->steps) n += (s.kind == S_CONV && s.conv.splitk > 1) ? 2 : (s.kind == S_FC ? fc_launches(s.M) : (s.kind == S_GAP ? 2 : 1));
+    for (const Step& s : net->steps) n += (s.kind == S_CONV) ? 1 + conv_reduce_launches(s.conv) : (s.kind == S_FC ? fc_launches(s.M) : (s.kind == S_GAP ? 2 : 1));
     if (head_fused_supported(net->N, net->t_last.C, net->fc_dims)) n -= 1 /* gap_finalize */ + (fc_launches(net->N) - 1) * 2;
     return n;
 }

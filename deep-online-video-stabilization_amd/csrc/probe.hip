@@ -41,20 +41,13 @@ __global__ __launch_bounds__(256) void probe_mfma_f32_kernel(float* __restrict__
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-// Eight 16-B loads in flight per lane, then the eight stores (one load per loop trip left the round-2 probe at 4.9 TB/s where
-// the hardware guide measures 6.3 for a float4 copy); grid = 8 resident blocks per CU, each wave-instruction 1 KiB contiguous.
+// One float4 per thread, non-temporal, the grid covers the buffer once (tools/copy_probe.hip, profiles/r03_copy_probe.txt: 6.53 TB/s;
+// plain loads / stores 6.20; a 2048-block grid-stride loop with 8 loads in flight per lane 4.4 -- its lanes revisit the same
+// channel interleave every trip; the round-2 probe, one load per trip of such a loop, 4.9; hipMemcpyDtoD 4.8).
 typedef float probe_f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void probe_copy_kernel(const probe_f32x4* __restrict__ src, probe_f32x4* __restrict__ dst, long n4) {
-    const long stride = (long)gridDim.x * 256;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 7 * stride < n4; i += 8 * stride) {
-        probe_f32x4 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(src + i + j * stride);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) __builtin_nontemporal_store(v[j], dst + i + j * stride);
-    }
-    for (; i < n4; i += stride) dst[i] = src[i];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 extern "C" {
@@ -73,8 +66,9 @@ double stabnet_probe_mfma_f32_flops(int blocks, int iters) {
 /* dst[i] = src[i], n_floats % 4 == 0; bytes moved = 8 * n_floats. */
 int stabnet_probe_hbm_copy(const float* src, float* dst, long n_floats, void* stream) {
     SN_REQUIRE(src && dst && n_floats > 0 && (n_floats & 3) == 0, "probe_hbm_copy: bad arguments");
-    probe_copy_kernel<<<256 * 8, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const probe_f32x4*>(src),
-                                                               reinterpret_cast<probe_f32x4*>(dst), n_floats / 4);
+    SN_REQUIRE(n_floats / 4 / 256 < (1L << 31), "probe_hbm_copy: buffer too large");
+    probe_copy_kernel<<<(unsigned)cdiv(n_floats / 4, 256), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const probe_f32x4*>(src),
+                                                                                         reinterpret_cast<probe_f32x4*>(dst), n_floats / 4);
     SN_LAUNCH_CHECK("probe_copy_kernel");
     return STABNET_OK;
 }

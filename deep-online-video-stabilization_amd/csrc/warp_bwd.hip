@@ -246,19 +246,28 @@ __global__ __launch_bounds__(1024) void warp_bwd_mesh_kernel(const float* __rest
 
 // interpolate() backward wrt the image: acc[tap] += w_tap * d_out as 64-bit fixed point (a scatter has no fixed order:
 // integer adds make the sum order-independent), then d_im (+)= acc in a second pass.
+// Tiling as the forward sampler (warp.hip): one wave = 128 consecutive pixels of a row, lane-strided, so the four atomic
+// instructions of a pixel column each cover 64 neighbouring accumulators (the flow is close to the identity) instead of
+// 16-B-strided ones: the atomics, not the arithmetic, set this kernel's time (180 us per step with 4 consecutive pixels per thread).
 __global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ ys,
                                                          const float* __restrict__ d_out, int H, int W, int C,
                                                          sn_u64* __restrict__ acc_fix) {
-    const int n = blockIdx.z;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int y = blockIdx.y * 4 + wv;
-    const int xb = blockIdx.x * 256 + lane * 4;
+    constexpr int PX = 2;
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int segs = (W + 64 * PX - 1) / (64 * PX);
+    const int wseg = blockIdx.x * 4 + wv;
+    const int y = wseg / segs;
     if (y >= H) return;
+    const int x0s = (wseg - y * segs) * (64 * PX);
     const size_t rowoff = ((size_t)n * H + y) * W;
     sn_u64* dimg = acc_fix + (size_t)n * H * W * C;
-    unsigned* poison = reinterpret_cast<unsigned*>(acc_fix + (size_t)gridDim.z * H * W * C);   // the word behind the accumulators
-    for (int e = 0; e < 4 && xb + e < W; ++e) {
-        const float xm = xs[rowoff + xb + e], ym = ys[rowoff + xb + e];
+    unsigned* poison = reinterpret_cast<unsigned*>(acc_fix + (size_t)gridDim.y * H * W * C);   // the word behind the accumulators
+#pragma unroll
+    for (int e = 0; e < PX; ++e) {
+        const int xx = x0s + e * 64 + lane;
+        if (xx >= W) continue;
+        const float xm = xs[rowoff + xx], ym = ys[rowoff + xx];
         const float xp = (xm + 1.0f) * (float)W / 2.0f, yp = (ym + 1.0f) * (float)H / 2.0f;
         int x0 = cvt_i32_x86_b(floorf(xp)), y0 = cvt_i32_x86_b(floorf(yp));
         int x1 = x0 + 1, y1 = y0 + 1;
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict
         const float wa = (x1f - xp) * (y1f - yp), wb = (x1f - xp) * (yp - y0f);
         const float wc = (xp - x0f) * (y1f - yp), wd = (xp - x0f) * (yp - y0f);
         for (int ch = 0; ch < C; ++ch) {
-            const float g = d_out[(rowoff + xb + e) * C + ch];
+            const float g = d_out[(rowoff + xx) * C + ch];
             if (g == 0.f) continue;                          // (NaN != 0: a NaN gradient goes on and poisons the sums)
             atomicAdd(&dimg[((size_t)y0 * W + x0) * C + ch], to_fix((double)(wa * g), poison));
             atomicAdd(&dimg[((size_t)y1 * W + x0) * C + ch], to_fix((double)(wb * g), poison));
@@ -398,100 +407,160 @@ __global__ __launch_bounds__(256) void feature_loss_kernel(const float* __restri
 //   losses[0] id2 = mean|theta| * id_mul      (s_net_bundle_nobm.py:263)      losses[1] black_pos (mean hinge^2 * use_black)
 //   losses[2] distortion (:166-181)           losses[3] consistency (:183-210)
 // d_theta = clip_mask * (d_pts2_warp + w_dist * d dist + w_cons * d cons + w_black * d black) + w_id * sign(theta)/(N*nt)
-// The per-sample vertex arrays are indexed dynamically: in LDS (template LDSV) they cost ~5 us, as private arrays they live
-// in scratch memory (128 us for 8 samples).
-template <bool LDSV>
-__global__ __launch_bounds__(64) void mesh_losses_kernel(const float* __restrict__ theta, const float* __restrict__ d_pts2_warp,
-                                                         int N, int gh, int gw, float lim, float id_mul, float w_id,
-                                                         float w_dist, float w_cons, float use_black, float w_black,
-                                                         float* __restrict__ losses, float* __restrict__ d_theta) {
-    const int n = threadIdx.x;
-    const int nv = (gh + 1) * (gw + 1), nt = nv * 2;
+// One block; a sample = 32 lanes, eight samples at a time.  Phases (barrier between them): vertices (clip + id term) -> LDS;
+// cells (distortion triples + the black hinge, corner gradients in registers) and per-vertex second differences -> LDS;
+// vertices GATHER their gradient from the (up to four) cells and the (up to twelve) second-difference terms that touch them, in a
+// fixed order: no read-modify-write chains (the first form -- one thread per sample walking every term and accumulating into an
+// LDS array -- spent 51 us per tower in ~1 600 dependent LDS updates; private arrays, indexed dynamically, land in scratch: 128 us).
+#define SN_ML_LANES 32
+#define SN_ML_SAMPLES 8
+__global__ __launch_bounds__(SN_ML_LANES * SN_ML_SAMPLES) void mesh_losses_kernel(
+    const float* __restrict__ theta, const float* __restrict__ d_pts2_warp, int N, int gh, int gw, float lim, float id_mul,
+    float w_id, float w_dist, float w_cons, float use_black, float w_black, float* __restrict__ losses, float* __restrict__ d_theta) {
+    constexpr int NVMAX = 81, NCMAX = 64;
+    __shared__ float sp[SN_ML_SAMPLES][2 * NVMAX];            // clipped vertices
+    __shared__ float sdc[SN_ML_SAMPLES][NCMAX][8];            // per cell: d/d corner q, axis d -> [2 q + d]
+    __shared__ float se[SN_ML_SAMPLES][NVMAX][4][2];          // second differences e(v, t, d) (0 where the term does not exist)
+    __shared__ float spart[SN_ML_SAMPLES][4][NVMAX];          // per vertex / per cell loss partials: id, black, dist, cons
     __shared__ float red[4][64];
-    float l_id = 0.f, l_black = 0.f, l_dist = 0.f, l_cons = 0.f;
-    extern __shared__ float mesh_lds[];
-    float p_priv[LDSV ? 1 : 2 * 81], dp_priv[LDSV ? 1 : 2 * 81];      // (gh+1)(gw+1) <= 81 vertices
-    float* const p = LDSV ? mesh_lds + (size_t)n * 4 * nv : p_priv;
-    float* const dp = LDSV ? p + 2 * nv : dp_priv;
-    if (n < N) {
-        const double hh = 2.0 / gh, ww = 2.0 / gw;
-        for (int i = 0; i <= gh; ++i)
-            for (int j = 0; j <= gw; ++j) {
-                const int v = i * (gw + 1) + j;
-                float px = (float)(j * ww - 1.0) + theta[(size_t)n * nt + 2 * v];
-                float py = (float)(i * hh - 1.0) + theta[(size_t)n * nt + 2 * v + 1];
-                p[2 * v] = fminf(fmaxf(px, -lim), lim);
-                p[2 * v + 1] = fminf(fmaxf(py, -lim), lim);
-                dp[2 * v] = dp[2 * v + 1] = 0.f;
-                l_id += fabsf(theta[(size_t)n * nt + 2 * v]) + fabsf(theta[(size_t)n * nt + 2 * v + 1]);
+    const int ls = threadIdx.x / SN_ML_LANES, l = threadIdx.x % SN_ML_LANES;
+    const int nv = (gh + 1) * (gw + 1), nt = nv * 2, cells = gh * gw;
+    const double hh = 2.0 / gh, ww = 2.0 / gw;
+    const float cb = 2.0f * use_black / (float)(N * gh * gw * 8);
+    const float kq0 = (float)(hh / ww), kq1 = (float)(ww / hh);
+    const float cd = 1.0f / (8.0f * (float)(N * gh * gw) * 2.0f);   // mean over [N*cells, 2] then / 8
+    int ncons = 0;
+    for (int i = 0; i <= gh; ++i)
+        for (int j = 0; j <= gw; ++j) ncons += (i > 1) + (j > 1) + (i < gh - 1) + (j < gw - 1);
+    const float cc = (ncons > 0) ? 1.0f / ((float)N * 2.0f * (float)ncons) : 0.f;
+    for (int n0 = 0; n0 < N; n0 += SN_ML_SAMPLES) {
+        const int n = n0 + ls;
+        const bool live = n < N;
+        // ---- A: vertices
+        if (live)
+            for (int v = l; v < nv; v += SN_ML_LANES) {
+                const int i = v / (gw + 1), j = v - i * (gw + 1);
+                const float tx = theta[(size_t)n * nt + 2 * v], ty = theta[(size_t)n * nt + 2 * v + 1];
+                sp[ls][2 * v] = fminf(fmaxf((float)(j * ww - 1.0) + tx, -lim), lim);
+                sp[ls][2 * v + 1] = fminf(fmaxf((float)(i * hh - 1.0) + ty, -lim), lim);
+                spart[ls][0][v] = fabsf(tx) + fabsf(ty);
             }
-        // black_pos hinge on pts1 entries (each cell corner): identically 0 after the clip, kept for fidelity
-        const float cb = 2.0f * use_black / (float)(N * gh * gw * 8);
-        // distortion: 8 ordered corner triples per cell, R = 90deg rotation scaled by the cell aspect k
-        const float kq0 = (float)(hh / ww), kq1 = (float)(ww / hh);
-        const float cd = 1.0f / (8.0f * (float)(N * gh * gw) * 2.0f);   // mean over [N*cells, 2] then / 8
-        const int trip[8][3] = {{0, 1, 3}, {1, 3, 2}, {3, 2, 0}, {2, 0, 1}, {1, 0, 2}, {0, 2, 3}, {2, 3, 1}, {3, 1, 0}};
-        for (int i = 0; i < gh; ++i)
-            for (int j = 0; j < gw; ++j) {
+        __syncthreads();
+        // ---- B: cells (8 ordered corner triples, R = 90 deg rotation scaled by the cell aspect k; black hinge on the corners)
+        if (live)
+            for (int c = l; c < cells; c += SN_ML_LANES) {
+                const int i = c / gw, j = c - i * gw;
                 const int vq[4] = {i * (gw + 1) + j, i * (gw + 1) + j + 1, (i + 1) * (gw + 1) + j, (i + 1) * (gw + 1) + j + 1};
-                for (int q = 0; q < 4; ++q)
-                    for (int d = 0; d < 2; ++d) {
-                        const float v = p[2 * vq[q] + d];
-                        const float e = (v > lim) ? v - lim : ((-lim > v) ? -lim - v : 0.f);
-                        l_black += e * e * use_black;
-                        if (e != 0.f) dp[2 * vq[q] + d] += w_black * cb * e * ((v > lim) ? 1.f : -1.f);
-                    }
+                float px[4], py[4], gx[4] = {0.f, 0.f, 0.f, 0.f}, gy[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { px[q] = sp[ls][2 * vq[q]]; py[q] = sp[ls][2 * vq[q] + 1]; }
+                float lb = 0.f, ld = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                 // identically 0 after the clip, kept for fidelity (s_net_bundle_nobm.py:139-146)
+                    const float ex = (px[q] > lim) ? px[q] - lim : ((-lim > px[q]) ? -lim - px[q] : 0.f);
+                    const float ey = (py[q] > lim) ? py[q] - lim : ((-lim > py[q]) ? -lim - py[q] : 0.f);
+                    lb += ex * ex * use_black;
+                    lb += ey * ey * use_black;
+                    if (ex != 0.f) gx[q] += w_black * cb * ex * ((px[q] > lim) ? 1.f : -1.f);
+                    if (ey != 0.f) gy[q] += w_black * cb * ey * ((py[q] > lim) ? 1.f : -1.f);
+                }
+                constexpr int trip[8][3] = {{0, 1, 3}, {1, 3, 2}, {3, 2, 0}, {2, 0, 1}, {1, 0, 2}, {0, 2, 3}, {2, 3, 1}, {3, 1, 0}};
+#pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    const int a0 = vq[trip[t][0]], a1 = vq[trip[t][1]], a2 = vq[trip[t][2]];
+                    const int a0 = trip[t][0], a1 = trip[t][1], a2 = trip[t][2];
                     const bool clock = t >= 4;
                     const float k = (t & 1) ? kq1 : kq0;
                     const float r01 = clock ? k : -k, r10 = clock ? -k : k;      // R = [[0,r01],[r10,0]]
-                    const float dx = p[2 * a1] - p[2 * a0], dy = p[2 * a1 + 1] - p[2 * a0 + 1];
-                    const float ex = r01 * dy - (p[2 * a2] - p[2 * a1]);
-                    const float ey = r10 * dx - (p[2 * a2 + 1] - p[2 * a1 + 1]);
-                    l_dist += ex * ex + ey * ey;
-                    const float gx = w_dist * cd * 2.0f * ex, gyv = w_dist * cd * 2.0f * ey;
+                    const float dx = px[a1] - px[a0], dy = py[a1] - py[a0];
+                    const float ex = r01 * dy - (px[a2] - px[a1]);
+                    const float ey = r10 * dx - (py[a2] - py[a1]);
+                    ld += ex * ex + ey * ey;
+                    const float gxx = w_dist * cd * 2.0f * ex, gyv = w_dist * cd * 2.0f * ey;
                     // ex = r01*(p1y - p0y) - p2x + p1x ; ey = r10*(p1x - p0x) - p2y + p1y
-                    dp[2 * a1 + 1] += gx * r01; dp[2 * a0 + 1] -= gx * r01; dp[2 * a2] -= gx; dp[2 * a1] += gx;
-                    dp[2 * a1] += gyv * r10; dp[2 * a0] -= gyv * r10; dp[2 * a2 + 1] -= gyv; dp[2 * a1 + 1] += gyv;
+                    gy[a1] += gxx * r01; gy[a0] -= gxx * r01; gx[a2] -= gxx; gx[a1] += gxx;
+                    gx[a1] += gyv * r10; gx[a0] -= gyv * r10; gy[a2] -= gyv; gy[a1] += gyv;
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { sdc[ls][c][2 * q] = gx[q]; sdc[ls][c][2 * q + 1] = gy[q]; }
+                spart[ls][1][c] = lb;
+                spart[ls][2][c] = ld;
             }
-        // consistency: squared second differences along both axes, from both ends
-        int ncons = 0;
-        for (int i = 0; i <= gh; ++i)
-            for (int j = 0; j <= gw; ++j) ncons += (i > 1) + (j > 1) + (i < gh - 1) + (j < gw - 1);
-        const float cc = (ncons > 0) ? 1.0f / ((float)N * 2.0f * (float)ncons) : 0.f;
-        for (int i = 0; i <= gh; ++i)
-            for (int j = 0; j <= gw; ++j) {
-                const int v = i * (gw + 1) + j;
-                const int nb[4][2] = {{(i - 1) * (gw + 1) + j, (i - 2) * (gw + 1) + j}, {i * (gw + 1) + j - 1, i * (gw + 1) + j - 2},
-                                      {(i + 1) * (gw + 1) + j, (i + 2) * (gw + 1) + j}, {i * (gw + 1) + j + 1, i * (gw + 1) + j + 2}};
+        // ---- B': second differences 2 p[nb0] - p[v] - p[nb1] along both axes, from both ends (s_net_bundle_nobm.py:183-210)
+        if (live)
+            for (int v = l; v < nv; v += SN_ML_LANES) {
+                const int i = v / (gw + 1), j = v - i * (gw + 1);
+                const int st[4] = {-(gw + 1), -1, gw + 1, 1};
                 const bool on[4] = {i > 1, j > 1, i < gh - 1, j < gw - 1};
-                for (int t = 0; t < 4; ++t) {
-                    if (!on[t]) continue;
+                float lc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
                     for (int d = 0; d < 2; ++d) {
-                        const float e = 2.0f * p[2 * nb[t][0] + d] - p[2 * v + d] - p[2 * nb[t][1] + d];
-                        l_cons += e * e;
-                        const float g = w_cons * cc * 2.0f * e;
-                        dp[2 * nb[t][0] + d] += 2.0f * g; dp[2 * v + d] -= g; dp[2 * nb[t][1] + d] -= g;
+                        float e = 0.f;
+                        if (on[t]) e = 2.0f * sp[ls][2 * (v + st[t]) + d] - sp[ls][2 * v + d] - sp[ls][2 * (v + 2 * st[t]) + d];
+                        se[ls][v][t][d] = e;
+                        lc += e * e;
+                    }
+                spart[ls][3][v] = lc;
+            }
+        __syncthreads();
+        // ---- C: every vertex gathers: cells around it (TL, TR, BL, BR of the vertex = that cell's corner BR, BL, TR, TL), then the
+        //      second-difference terms in which it is the centre (-g), the near neighbour (+2g) or the far neighbour (-g)
+        if (live)
+            for (int v = l; v < nv; v += SN_ML_LANES) {
+                const int i = v / (gw + 1), j = v - i * (gw + 1);
+                float g[2] = {0.f, 0.f};
+#pragma unroll
+                for (int qc = 0; qc < 4; ++qc) {
+                    const int ci = i - 1 + (qc >> 1), cj = j - 1 + (qc & 1);       // cell whose corner (3 - qc) is this vertex
+                    if (ci < 0 || cj < 0 || ci >= gh || cj >= gw) continue;
+                    const int corner = 3 - qc;
+                    g[0] += sdc[ls][ci * gw + cj][2 * corner];
+                    g[1] += sdc[ls][ci * gw + cj][2 * corner + 1];
+                }
+                const int st[4] = {-(gw + 1), -1, gw + 1, 1};
+                const float kc = w_cons * cc * 2.0f;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) g[d] -= kc * se[ls][v][t][d];                        // centre of (v, t)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {                                                    // near neighbour of (v - st, t)
+                        const int u = v - st[t];
+                        const int ui = i - ((t == 0) ? -1 : (t == 2) ? 1 : 0), uj = j - ((t == 1) ? -1 : (t == 3) ? 1 : 0);
+                        if (ui >= 0 && ui <= gh && uj >= 0 && uj <= gw) g[d] += 2.0f * (kc * se[ls][u][t][d]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {                                                    // far neighbour of (v - 2 st, t)
+                        const int u = v - 2 * st[t];
+                        const int ui = i - 2 * ((t == 0) ? -1 : (t == 2) ? 1 : 0), uj = j - 2 * ((t == 1) ? -1 : (t == 3) ? 1 : 0);
+                        if (ui >= 0 && ui <= gh && uj >= 0 && uj <= gw) g[d] -= kc * se[ls][u][t][d];
                     }
                 }
+                // clip mask + id loss
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const float th = theta[(size_t)n * nt + 2 * v + d];
+                    const float raw = ((d == 0) ? (float)(j * ww - 1.0) : (float)(i * hh - 1.0)) + th;
+                    const bool pass = (raw >= -lim) && (raw <= lim);
+                    float gg = g[d] + (d_pts2_warp ? d_pts2_warp[((size_t)n * nv + v) * 2 + d] : 0.f);
+                    gg = pass ? gg : 0.f;
+                    gg += w_id * id_mul * ((th > 0.f) ? 1.f : ((th < 0.f) ? -1.f : 0.f)) / (float)(N * nt);
+                    if (d_theta != nullptr) d_theta[(size_t)n * nt + 2 * v + d] = gg;
+                }
             }
-        l_dist *= cd; l_cons *= cc; l_black /= (float)(N * gh * gw * 8);
-        // clip mask + id loss
-        for (int v = 0; v < nv; ++v)
-            for (int d = 0; d < 2; ++d) {
-                const float th = theta[(size_t)n * nt + 2 * v + d];
-                const float raw = ((d == 0) ? (float)((v % (gw + 1)) * ww - 1.0) : (float)((v / (gw + 1)) * hh - 1.0)) + th;
-                const bool pass = (raw >= -lim) && (raw <= lim);
-                float g = dp[2 * v + d] + (d_pts2_warp ? d_pts2_warp[((size_t)n * nv + v) * 2 + d] : 0.f);
-                g = pass ? g : 0.f;
-                g += w_id * id_mul * ((th > 0.f) ? 1.f : ((th < 0.f) ? -1.f : 0.f)) / (float)(N * nt);
-                if (d_theta != nullptr) d_theta[(size_t)n * nt + 2 * v + d] = g;
-            }
+        // ---- per-sample loss sums in index order
+        if (live && l < 4) {
+            const int cnt = (l == 0 || l == 3) ? nv : cells;
+            float sacc = 0.f;
+            for (int k = 0; k < cnt; ++k) sacc += spart[ls][l][k];
+            if (l == 2) sacc *= cd;
+            if (l == 3) sacc *= cc;
+            if (l == 1) sacc /= (float)(N * gh * gw * 8);
+            red[l][n] = sacc;
+        }
+        __syncthreads();
     }
-    red[0][threadIdx.x] = l_id; red[1][threadIdx.x] = l_black; red[2][threadIdx.x] = l_dist; red[3][threadIdx.x] = l_cons;
-    __syncthreads();
     if (threadIdx.x < 4) {
         float s = 0.f;
         for (int i = 0; i < N; ++i) s += red[threadIdx.x][i];
@@ -542,7 +611,7 @@ int stabnet_interp_bwd(const float* x, const float* y, const float* d_out, int N
         stabnet_set_error("interp_bwd: memset failed");
         return STABNET_ERR_LAUNCH;
     }
-    dim3 grid(cdiv(W, 256), cdiv(H, 4), N);
+    dim3 grid(cdiv((long)cdiv(W, 128) * H, 4), N, 1);
     interp_bwd_kernel<<<grid, 256, 0, st>>>(x, y, d_out, H, W, C, static_cast<sn_u64*>(workspace));
     SN_LAUNCH_CHECK("interp_bwd_kernel");
     fix_to_float_kernel<<<cdiv(total, 256), 256, 0, st>>>(static_cast<const sn_u64*>(workspace), total, d_im, accumulate);
@@ -621,13 +690,8 @@ int stabnet_mesh_losses(const float* theta, const float* d_pts2_warp, int N, int
                         float* losses4, float* d_theta, void* stream) {
     SN_REQUIRE(theta && losses4, "mesh_losses: null pointer");
     SN_REQUIRE(N > 0 && N <= 64 && (grid_h + 1) * (grid_w + 1) <= 81 && do_crop_rate > 0.f, "mesh_losses: bad shape");
-    const size_t lds = (size_t)N * 4 * (grid_h + 1) * (grid_w + 1) * sizeof(float);
-    if (lds <= 60 * 1024)
-        mesh_losses_kernel<true><<<1, 64, lds, (hipStream_t)stream>>>(theta, d_pts2_warp, N, grid_h, grid_w, 1.0f / do_crop_rate,
-                                                                      id_mul, w_id, w_dist, w_cons, use_black, w_black, losses4, d_theta);
-    else
-        mesh_losses_kernel<false><<<1, 64, 0, (hipStream_t)stream>>>(theta, d_pts2_warp, N, grid_h, grid_w, 1.0f / do_crop_rate,
-                                                                     id_mul, w_id, w_dist, w_cons, use_black, w_black, losses4, d_theta);
+    mesh_losses_kernel<<<1, SN_ML_LANES * SN_ML_SAMPLES, 0, (hipStream_t)stream>>>(theta, d_pts2_warp, N, grid_h, grid_w, 1.0f / do_crop_rate,
+                                                                                id_mul, w_id, w_dist, w_cons, use_black, w_black, losses4, d_theta);
     SN_LAUNCH_CHECK("mesh_losses_kernel");
     return STABNET_OK;
 }
