@@ -21,3 +21,30 @@ def test_bad_argument_status_without_gpu():
     assert L.stabnet_interp_fwd(0, 0, 0, 1, 4, 4, 1, 0, 0) == -1
     assert b"null" in L.stabnet_last_error()
     assert L.stabnet_warp_fwd(1, 1, 0, 4, 4, 1, 4, 4, 0.8, 1, 1, 1, 1, 1, 0, 0) == -1
+
+
+def test_plan_level_host_logic_without_gpu():
+    """Plans are host objects: launch counts, workspace sizes and the training debug offsets need no GPU.  The 720p deploy frame
+    is 69 launches with the shipped split-K table (49 conv launches incl. the merged shortcut|conv1 ones, their split-K reduce
+    launches -- three-slice layers on the ring kernel reduce inside their workgroups --, assembly, pool, gap partials, fc_1..3,
+    output layer + mesh, sampler + push)."""
+    import ctypes as C
+    from stabnet_amd import _lib
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.stabnet_net_create(C.byref(h), 1, 720, 1280, 13, 50, 0) == 0
+    n_plan = L.stabnet_net_num_launches(h)
+    n_frame = L.stabnet_deploy_frame_launches(h, 4, 4)
+    assert n_frame == n_plan + 1                         # stack assembly for the pad step, + sampler; the mesh rides with the output layer
+    assert 55 <= n_frame <= 72, n_frame                  # (the exact count follows the measured split-K table: 69 today)
+    assert L.stabnet_net_workspace_bytes(h) > 100 << 20 and abs(L.stabnet_net_flops(h) / 142.94e9 - 1) < 1e-3
+    off, cnt = C.c_long(), C.c_long()
+    assert L.stabnet_net_train_debug_offset(h, b"argmax", C.byref(off), C.byref(cnt)) == -1      # not a keep_activations plan
+    L.stabnet_net_destroy(h)
+    t = C.c_void_p()
+    assert L.stabnet_net_create(C.byref(t), 2, 64, 96, 13, 50, 1) == 0
+    assert L.stabnet_net_train_debug_offset(t, b"argmax", C.byref(off), C.byref(cnt)) == 0 and cnt.value == 2 * 16 * 24 * 64
+    assert L.stabnet_net_train_debug_offset(t, b"fcx1", C.byref(off), C.byref(cnt)) == 0 and cnt.value == 2 * 2 * 2048
+    assert L.stabnet_net_train_debug_offset(t, b"bn:0", C.byref(off), C.byref(cnt)) == 0 and cnt.value == 2 * 16 * 24 * 64
+    assert L.stabnet_net_train_debug_offset(t, b"nonsense", C.byref(off), C.byref(cnt)) == -1
+    L.stabnet_net_destroy(t)
