@@ -71,3 +71,56 @@ def test_conv2d_matches_oracle(cuda, N, H, W, Cin, Cout, k, stride, pad, prologu
     scale = np.abs(want).max()
     err = np.abs(got - want).max()
     assert err <= (4e-5 if out_bn else 2e-5) * scale, "max err %g (scale %g)" % (err, scale)
+
+
+# N,H,W,Cin,Cout,k,stride,pad, bias, residual, relu   -- ring-eligible shapes (no prologue, Cin % 32 == 0) whose K-step count is a
+# multiple of 3: with split-K forced to 3 they run the in-workgroup form (conv_ring_kernel.h KG = 3: three 4-wave groups, LDS
+# reduction, full epilogue by group 0)
+KG_CASES = [
+    (1, 9, 16, 96, 64, 1, 1, 0, False, 0, False),       # 1x1, 3 K-steps (one per group), a single ragged M tile
+    (1, 17, 23, 192, 96, 1, 1, 0, True, 1, True),       # 1x1, 6 steps, ragged M and a ragged Cout tile, bias + residual + ReLU
+    (1, 30, 30, 64, 64, 3, 1, 1, False, 0, False),      # 3x3 SAME (zero-page taps), 18 steps
+    (2, 36, 64, 64, 128, 3, 1, 1, True, 1, True),       # 3x3, 72 x 2 tiles
+    (1, 37, 63, 128, 128, 3, 2, 1, True, 0, True),      # 3x3 stride 2, odd sizes, 36 steps
+    (1, 60, 60, 256, 256, 3, 1, 1, False, 1, False),    # the block-3 shape of a 720p frame: 57 x 4 tiles, 72 steps
+    (1, 150, 160, 96, 64, 1, 1, 0, True, 0, False),     # 375 tiles > 256 CUs: several tiles per workgroup (ring across tile boundaries)
+]
+
+
+@pytest.mark.parametrize("out_bn", [False, True])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad,bias,res,relu", KG_CASES)
+def test_split_k_inside_the_workgroup(cuda, N, H, W, Cin, Cout, k, stride, pad, bias, res, relu, out_bn):
+    from stabnet_amd import _lib, ops
+    rng = np.random.default_rng(Cin * 5 + Cout + k + H)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32) if bias else None
+    want = O.conv2d(x, w, stride, ((pad, pad), (pad, pad)), b)
+    r = None
+    if res:
+        r = rng.standard_normal(want.shape).astype(np.float32)
+        want = want + r
+    osc = osh = None
+    if out_bn:
+        osc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+        osh = (rng.standard_normal(Cout) * 0.3).astype(np.float32)
+        want = (want * osc + osh).astype(np.float32)
+    if relu:
+        want = np.maximum(want, 0)
+    t = lambda v: None if v is None else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(cuda)
+    args = (t(x), t(ops.pack_conv_weight(w)), t(b), None, None, t(r), 1, stride, pad, relu)
+    L = _lib.lib()
+    try:
+        L.stabnet_conv_tuning_override(2, 3)             # the 64 x 64 tile, three K slices
+        got3 = ops.conv2d(*args, out_scale=t(osc), out_shift=t(osh)).cpu().numpy()
+        got3b = ops.conv2d(*args, out_scale=t(osc), out_shift=t(osh)).cpu().numpy()
+        L.stabnet_conv_tuning_override(2, 1)
+        got1 = ops.conv2d(*args, out_scale=t(osc), out_shift=t(osh)).cpu().numpy()
+    finally:
+        L.stabnet_conv_tuning_override(-1, -1)
+    scale = np.abs(want).max()
+    for got in (got3, got1):
+        assert got.shape == want.shape and np.isfinite(got).all()
+        assert np.abs(got - want).max() <= (4e-5 if out_bn else 2e-5) * scale
+    assert np.array_equal(got3, got3b)                   # groups are added in group order: the same bits every time
+    assert np.abs(got3 - got1).max() <= 1e-5 * scale     # three slices vs one: float32 summation order only
