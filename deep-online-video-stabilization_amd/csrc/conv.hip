@@ -300,6 +300,34 @@ static int launch_ring_kg3(const ConvArgs& a, hipStream_t st) {
     return STABNET_OK;
 }
 
+// The ring kernel's PRO form (conv_ring_kernel.h): 1x1 / stride 1 convolutions whose input carries a BN + ReLU prologue and whose
+// epilogue has no consumer BN (the training forward).  `delta` != 0: the pair of towers as one launch (ConvPair::dscale).
+// Measured: the 36 paired 1x1 launches of the 8 x 288 x 512 step 61.2 -> 55.9 us (76 -> 82.8 TF), 494.7 -> 502.2 pairs/s.  The
+// inference conv1 layers (prologue AND consumer BN) were tried on it too: 25.7 us against 23.5 / 28.7 us on the register-staged
+// kernel, the same 310 us per frame in sum -- they stay where they were.
+static bool ring_pro_eligible(const ConvArgs& a) {
+    static const int on = env_int("STABNET_CONV_RING_PRO", 1);
+    if (g_ring < 0) g_ring = env_int("STABNET_CONV_RING", 1);
+    return on && g_ring && !g_bf16_operands && !g_force_bk16 && a.in_scale != nullptr && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 &&
+           a.up == 1 && a.Cin % 32 == 0 && a.out_scale == nullptr && a.out_floor == nullptr && !a.rowrun && a.x_ld == a.Cin;
+}
+static int launch_ring_pro(ConvArgs a, long delta, hipStream_t st) {
+    if (g_ring_wgs == 0) {
+        const int cus = device_cus();
+        if (cus <= 0) {
+            stabnet_set_error("conv: cannot read the CU count");
+            return STABNET_ERR_LAUNCH;
+        }
+        g_ring_wgs = env_int("STABNET_CONV_RING_WGS_PER_CU", 3) * cus;
+    }
+    a.out_floor = reinterpret_cast<const float*>((size_t)delta);      // the kernel's pair distance (not a pointer: see conv_ring_kernel.h PRO)
+    const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64) * a.splitk;
+    const int grid = (int)std::min<long>(ntiles, g_ring_wgs);
+    conv_ring_f32_kernel<0, 0, 1, 1><<<grid, 256, 0, st>>>(a);
+    SN_LAUNCH_CHECK("conv_ring_f32_kernel<PRO>");
+    return STABNET_OK;
+}
+
 // 1 if conv_launch() of this (planned) convolution is followed by a split-K reduce launch (plan-time view: the prologue is known
 // from in_scale_expected)
 int conv_reduce_launches(const ConvArgs& a) {
@@ -326,7 +354,10 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands
     const bool ring = ring_eligible(a, t);
     SN_REQUIRE(ring || a.x_ld == a.Cin, "conv: a strided input (x_ld %d != Cin %d) needs the ring kernel", a.x_ld, a.Cin);
     const int kg = (t == T64x64) ? conv_kgroups(a, ring) : 1;
-    if (kg > 1) {
+    const bool pro = !ring && t == T64x64 && bk32 && ring_pro_eligible(a);
+    if (pro) {
+        rc = launch_ring_pro(a, 0, st);
+    } else if (kg > 1) {
         rc = launch_ring_kg3(a, st);
     } else if (ring) {
         rc = launch_ring(a, st);
@@ -341,7 +372,9 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands
     }
     const int mode = (a.up > 1 || a.rowrun) ? 2 : (a.pad == 0 ? 0 : 1);
     int kind = PK_KERNEL_CONV_RING + mode + (bf16_operands ? 3 : 0);
-    if (kg > 1) {
+    if (pro) {
+        kind = PK_KERNEL_CONV_KG + 2;
+    } else if (kg > 1) {
         kind = PK_KERNEL_CONV_KG + mode;
     } else if (!ring) {                                                  // + 18 for the one-stage (NBUF = 1), + 36 for the bf16-operand instantiation
         int bm, bn, nbuf, bf16;
@@ -393,9 +426,14 @@ int conv_launch_pair(const ConvArgs& a, const ConvPair& pr, hipStream_t st, Prof
     const int mode = a.pad == 0 ? 0 : 1;
     const bool rec = prof != nullptr && prof->begin(st);
     int rc;
-    if (bk32) rc = mode == 0 ? launch_pair_one<32, 0>(a, pr, st) : launch_pair_one<32, 1>(a, pr, st);
+    // 1x1 layers: the LDS-DMA ring kernel with the BN + ReLU prologue on the A fragments (both towers in one launch: the offsets of
+    // the second tower all derive from the distance of the two workspaces, which must be what ConvPair describes)
+    const bool pro = bk32 && ring_pro_eligible(a) && pr.dx == pr.dscale - (long)pr.m_tower * a.Cin && pr.dy == pr.dscale - (long)pr.m_tower * a.Cout &&
+                     (a.residual == nullptr || pr.dres == pr.dscale - (long)(a.N / 2) * a.res_H * a.res_W * a.res_ld);
+    if (pro) rc = launch_ring_pro(a, pr.dscale, st);
+    else if (bk32) rc = mode == 0 ? launch_pair_one<32, 0>(a, pr, st) : launch_pair_one<32, 1>(a, pr, st);
     else rc = mode == 0 ? launch_pair_one<16, 0>(a, pr, st) : launch_pair_one<16, 1>(a, pr, st);
-    if (rec) prof->end(st, PK_KERNEL_CONV_PAIR + mode * 2 + (bk32 ? 1 : 0), 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
+    if (rec) prof->end(st, pro ? PK_KERNEL_CONV_KG + 2 : PK_KERNEL_CONV_PAIR + mode * 2 + (bk32 ? 1 : 0), 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
                        4.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.K * a.Cout + (double)a.M * a.Cout * a.splitk),
                        a.M, a.Cout, a.K, a.splitk);
     if (rc) return rc;

@@ -64,11 +64,13 @@ constexpr int SN_EPI_WAVE_BYTES = 32 * 32 * 4;
 #define SN_EPI_R(q, dst) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(rd), "n"((q) * 1024) : "memory")
 
 // NOSPLIT: p.splitk > 1 describes a split INSIDE the workgroup (the accumulators handed in are already the full sum): full epilogue.
-template <int TM, int TN, bool NOSPLIT = false>
+// OFFS (the ring kernel's PRO form, a tile of the second tower of a pair): y and the residual live y_off / res_off elements
+// further on; out_floor is not a floor there.
+template <int TM, int TN, bool NOSPLIT = false, bool OFFS = false>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& p, int mw0, int nw0, int lane, int z,
-                                              unsigned scratch) {
+                                              unsigned scratch, long y_off = 0, long res_off = 0) {
     const bool split = !NOSPLIT && p.splitk > 1;
-    float* const outp = split ? p.partial + (size_t)z * p.M * p.Cout : p.y;
+    float* const outp = split ? p.partial + (size_t)z * p.M * p.Cout : (OFFS ? p.y + y_off : p.y);
     const bool has_res = !split && p.residual != nullptr;
     const bool has_obn = !split && p.out_scale != nullptr;
     const bool has_bias = !split && p.bias != nullptr;
@@ -102,13 +104,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvA
             float4 rv[4];
             if (has_res) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const float4*>(p.residual + (roff[q] + (unsigned)nc));
+                for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const float4*>((OFFS ? p.residual + res_off : p.residual) + (roff[q] + (unsigned)nc));
             }
             const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 bv = has_bias ? *reinterpret_cast<const float4*>(p.bias + nc) : zero4;
             const float4 os = has_obn ? *reinterpret_cast<const float4*>(p.out_scale + nc) : zero4;
             const float4 ob = has_obn ? *reinterpret_cast<const float4*>(p.out_shift + nc) : zero4;
-            const bool has_floor = has_obn && p.out_floor != nullptr;
+            const bool has_floor = !OFFS && has_obn && p.out_floor != nullptr;
             const float4 fl = has_floor ? *reinterpret_cast<const float4*>(p.out_floor + nc) : zero4;
             {
                 const f32x16 a = acc[i][j];

@@ -25,6 +25,15 @@
 //            have just retired, one barrier, group 0 adds them in group order and runs the FULL epilogue: no partial slabs in
 //            HBM and no reduce launch (4.6 us + a 12 MB round trip per split-K layer of the 720p frame).  One workgroup per
 //            CU keeps 12 waves resident, as three co-resident split-K workgroups did.
+//   PRO = 1: the A operand gets a per-channel prologue a = relu(a * scale[k] + shift[k]) (batch-statistics BN + ReLU of the training
+//            forward, s_net_bundle_nobm.py:301) WITHOUT leaving the LDS-DMA path: 1x1 convolutions only (k = input channel).  Every
+//            wave DMAs the step's 32 scales + 32 shifts (256 B) into its own corner of LDS with the stage (5 DMAs per wave and
+//            stage instead of 4), reads the 4 + 4 values of its fragment next to the fragment itself and applies fma + max on
+//            the fragment registers (8 VALU per 4 MFMAs; same arithmetic as the register-staged kernel's prologue).  The PAIR of
+//            siamese towers runs as one launch (p.M = both towers' rows): `p.out_floor` -- unused here, there is no consumer BN in
+//            training -- carries the element distance between the two towers' workspaces as an integer; tiles of the second tower
+//            shift x / y / residual / scale / shift by it (minus the rows the pair index has already advanced by), exactly as
+//            conv_igemm_f32_pair_kernel does with its ConvPair argument.
 #pragma once
 #include "conv_kernel.h"
 #include <type_traits>
@@ -55,11 +64,14 @@ typedef __bf16 sn_bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int MODE /* 0: no padding, 1: zero padding, 2: row-run A operand on a zero-BORDERED image (ConvArgs::rowrun) */,
           int BF16 = 0 /* 1: fragments rounded to bf16 at read time, v_mfma_f32_32x32x16_bf16 (conv_launch's bf16_operands) */,
-          int KG = 1 /* K groups of 4 waves: split-K inside the workgroup (p.splitk == KG), see the header comment */>
+          int KG = 1 /* K groups of 4 waves: split-K inside the workgroup (p.splitk == KG), see the header comment */,
+          int PRO = 0 /* 1: BN + ReLU prologue on the A fragments (MODE 0, KG 1 only), pair of towers as one launch */>
 __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs p) {
     constexpr int BM = 64, BN = 64, BK = 32;
     constexpr int STAGE = (BM + BN) * BK;                  // floats
-    __shared__ __attribute__((aligned(16))) float ring[KG * 3 * STAGE];
+    static_assert(!PRO || (MODE == 0 && KG == 1 && BF16 == 0), "the fragment prologue exists for the plain 1x1 fp32 kernel");
+    constexpr int SC_FLOATS = PRO ? 3 * 4 * 64 : 0;        // per stage and wave: 32 scales + 32 shifts, behind the ring
+    __shared__ __attribute__((aligned(16))) float ring[KG * 3 * STAGE + SC_FLOATS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (KG > 1) ? ((tid >> 6) & 3) : (tid >> 6);
     const int grp = (KG > 1) ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;      // K group = K slice of this wave
@@ -87,6 +99,10 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     const int last_slice_steps = total_steps - (p.splitk - 1) * p.steps_per_split;
     const unsigned lds_base = (unsigned)(size_t)(sn_lds_ptr_t)ring + (KG > 1 ? (unsigned)grp * (3u * STAGE * 4u) : 0u);   // this group's ring
 
+    // PRO: the pair of towers (see the header comment)
+    const long pair_delta = PRO ? (long)(size_t)p.out_floor : 0L;
+    const int m_tower = (PRO && pair_delta != 0) ? (p.M >> 1) : 0x7fffffff;
+    const unsigned sc_base = lds_base + 3u * STAGE * 4u;   // [slot][wave][scale 32 | shift 32]
     // consumer steps of this workgroup (every slice has steps_per_split steps except the last one)
     int remaining = 0;
     for (int t = t_first; t < t_end; t += t_stride) remaining += (t / tiles_mn == p.splitk - 1) ? last_slice_steps : p.steps_per_split;
@@ -105,6 +121,8 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     unsigned long long a_mask[2];                          // MODE 1: tap bits per row
     int l_tap = 0, l_c0 = 0, l_kw = 0;                     // MODE 2: l_tap = filter row kh, l_kw = 32-float step inside its run
     const float *xb = p.x, *wb = p.w;
+    const float* scb = p.in_scale;                         // PRO: running pointer of the step's 32 scales (shifts at a constant byte distance)
+    const unsigned sc_voff = PRO ? (unsigned)((lane & 31) * 4) + ((lane >> 5) ? (unsigned)((p.in_shift - p.in_scale) * 4) : 0u) : 0u;
     auto producer_setup = [&]() {
         const int z = (KG > 1) ? grp : pt / tiles_mn;
         const int mn = (KG > 1) ? pt : pt - z * tiles_mn;
@@ -171,6 +189,11 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
             l_kw = l_tap - l_kh * p.KW;
             xb = p.x + ((l_kh * p.W + l_kw) * ld + l_c0 - pad_off);
             wb = p.w + (l_tap * p.Cin + l_c0);
+            if constexpr (PRO) {
+                const bool t2 = m0 >= m_tower;             // tile of the second tower: its tensors live `pair_delta` floats further on
+                if (t2) xb += pair_delta - (long)m_tower * ld;
+                scb = p.in_scale + l_c0 + (t2 ? pair_delta : 0L);
+            }
         }
     };
     // Issue one stage into ring slot `slot` (no-op when every tile of this workgroup has been issued), in four parts so
@@ -187,6 +210,15 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
         const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
         const float* base = reinterpret_cast<const float*>((size_t)(((unsigned long long)hi << 32) | lo));
         asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(base), "s"(lds_byte) : "memory", "m0");
+    };
+    auto issue_s = [&](int slot) {                         // PRO: this wave's copy of the step's scales | shifts (4 B per lane)
+        if (pt >= t_end) return;
+        const unsigned long long b64 = (unsigned long long)(size_t)scb;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+        const float* base = reinterpret_cast<const float*>((size_t)(((unsigned long long)hi << 32) | lo));
+        const unsigned lds_byte = (unsigned)__builtin_amdgcn_readfirstlane((int)(sc_base + (unsigned)(slot * 1024 + wave * 256)));
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" ::"v"(sc_voff), "s"(base), "s"(lds_byte) : "memory", "m0");
     };
     auto issue_a = [&](int slot, int t) {
         if (pt >= t_end || (RING_ABLATE & 1)) return;
@@ -212,6 +244,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
         }
         xb += BK;
         wb += BK;
+        if constexpr (PRO) scb += BK;
         if constexpr (MODE == 2) {
             if (++l_kw == run_steps) { l_kw = 0; ++l_tap; xb += (p.W + 2 * p.pad) * p.Cin - BK * run_steps; }
             return;
@@ -228,7 +261,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     auto issue_part = [&](int slot, int part) {
         if (part == 0) issue_a(slot, 0);
         else if (part == 1) { issue_a(slot, 1); issue_b(slot, 0); }
-        else if (part == 2) issue_b(slot, 1);
+        else if (part == 2) { issue_b(slot, 1); if constexpr (PRO) issue_s(slot); }
         else issue_advance();
     };
     auto issue = [&](int slot) {
@@ -237,6 +270,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 
     // ---- consumer state: the tile being accumulated
     int ct = t_first, c_left = 0, c_m0 = 0, c_n0 = 0, c_z = 0;
+    long c_yoff = 0, c_roff = 0;                           // PRO: element offsets of y / residual for a tile of the second tower
     auto consumer_setup = [&]() {
         c_z = (KG > 1) ? grp : ct / tiles_mn;
         const int mn = (KG > 1) ? ct : ct - c_z * tiles_mn;
@@ -244,6 +278,11 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
         c_m0 = mt * BM;
         c_n0 = (mn - mt * tiles_n) * BN;
         c_left = (c_z == p.splitk - 1) ? last_slice_steps : p.steps_per_split;
+        if constexpr (PRO) {
+            const bool t2 = c_m0 >= m_tower;
+            c_yoff = t2 ? pair_delta - (long)m_tower * p.Cout : 0L;
+            c_roff = t2 ? pair_delta - (long)(p.N >> 1) * p.res_H * p.res_W * p.res_ld : 0L;
+        }
     };
 
     // ---- fragment read addresses (LDS bytes, stage 0) of the 4 kk sub-steps: lane (i = lane&31, h = lane>>5) reads
@@ -284,6 +323,23 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 #define SN_READ1(kk, off) do { SN_DS_READ(a1, SN_RA1, a_frag[kk], off); SN_DS_READ(b1, SN_RB1, b_frag[kk], off); } while (0)
 #define SN_WAIT0() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA0(a0), "+" SN_RB0(b0))
 #define SN_WAIT1() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA1(a1), "+" SN_RB1(b1))
+    // PRO: the fragment's 4 scales + 4 shifts ride with it (this wave's own copy: offset slot * 1024 selects the stage)
+#define SN_RS0 "{v[116:119]}"
+#define SN_RH0 "{v[120:123]}"
+#define SN_RS1 "{v[124:127]}"
+#define SN_RH1 "{v[128:131]}"
+#define SN_READ0P(kk, off, soff)                                                                      \
+    do { SN_READ0(kk, off); SN_DS_READ(sc0, SN_RS0, s_frag[kk], soff); SN_DS_READ(sh0, SN_RH0, s_frag[kk], (soff) + 128); } while (0)
+#define SN_READ1P(kk, off, soff)                                                                      \
+    do { SN_READ1(kk, off); SN_DS_READ(sc1, SN_RS1, s_frag[kk], soff); SN_DS_READ(sh1, SN_RH1, s_frag[kk], (soff) + 128); } while (0)
+#define SN_WAIT0P() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA0(a0), "+" SN_RB0(b0), "+" SN_RS0(sc0), "+" SN_RH0(sh0))
+#define SN_WAIT1P() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA1(a1), "+" SN_RB1(b1), "+" SN_RS1(sc1), "+" SN_RH1(sh1))
+#define SN_PRO(a, sc, sh)                                                                             \
+    do {                                                                                              \
+        a.x = fmaxf(__builtin_fmaf(a.x, sc.x, sh.x), 0.f); a.y = fmaxf(__builtin_fmaf(a.y, sc.y, sh.y), 0.f); \
+        a.z = fmaxf(__builtin_fmaf(a.z, sc.z, sh.z), 0.f); a.w = fmaxf(__builtin_fmaf(a.w, sc.w, sh.w), 0.f); \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
 #define SN_MFMA1(a, b, c)                                                                                      \
     do {                                                                                                       \
         if (!(RING_ABLATE & 8)) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.c, b.c, acc[0][0], 0, 0, 0); \
@@ -305,15 +361,22 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     // registers, so the barrier (a) publishes stage k+1, (b) frees slot k % 3 for stage k+3.  At a tile's last step the
     // freed slot first serves as the epilogue's transposition scratch; stage k+3 is issued after it, behind one more barrier.
     f32x4 a0, b0, a1, b1;
+    f32x4 sc0, sh0, sc1, sh1;                              // PRO only
+    unsigned s_frag[4] = {0u, 0u, 0u, 0u};
+    if constexpr (PRO) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) s_frag[kk] = sc_base + (unsigned)(wave * 256 + (8 * kk + 4 * (lane >> 5)) * 4);
+    }
     if (RING_ABLATE & 4) { a0 = b0 = a1 = b1 = f32x4{1.f, 2.f, 3.f, 4.f}; }
     issue(0);
     issue(1);
-    if (remaining > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // (a wave has 4 DMAs per stage in flight, 5 with the scales of the PRO form)
+    if (remaining > 1) { if constexpr (PRO) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SN_BARRIER();
     SN_STAMP(1);
     issue(2);
-    SN_READ0(0, 0);
+    if constexpr (PRO) SN_READ0P(0, 0, 0); else SN_READ0(0, 0);
 
     // One K-step on ring slot SLOT; returns false after the workgroup's last step.
     auto step = [&](auto slot_c) -> bool {
@@ -355,6 +418,51 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(cl, ch, 0, 1, 2, 3, 4, 5, 6, 7),
                                                                 __builtin_shufflevector(dl, dh, 0, 1, 2, 3, 4, 5, 6, 7), acc[0][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (PRO) {
+        // the fp32 schedule of the branch below; the prologue of fragment kk + 1 (8 VALU) sits in front of the LAST MFMA of group
+        // kk -- in the shadow of the one before it -- so only the step's first fragment pays for its prologue in the open
+        constexpr int SOFF = SLOT * 1024, SOFF_NEXT = ((SLOT + 1) % 3) * 1024;
+        SN_WAIT0P();
+        SN_PRO(a0, sc0, sh0);
+        SN_MFMA1(a0, b0, x);
+        SN_READ1P(1, OFF, SOFF);
+        SN_MFMA1(a0, b0, y);
+        SN_MFMA1(a0, b0, z);
+        SN_WAIT1P();
+        SN_PRO(a1, sc1, sh1);
+        SN_MFMA1(a0, b0, w);
+        SN_MFMA1(a1, b1, x);
+        SN_READ0P(2, OFF, SOFF);
+        SN_MFMA1(a1, b1, y);
+        SN_MFMA1(a1, b1, z);
+        SN_WAIT0P();
+        SN_PRO(a0, sc0, sh0);
+        SN_MFMA1(a1, b1, w);
+        SN_MFMA1(a0, b0, x);
+        SN_READ1P(3, OFF, SOFF);
+        SN_MFMA1(a0, b0, y);
+        SN_MFMA1(a0, b0, z);
+        SN_WAIT1P();                                       // every fragment of this stage is in registers
+        SN_PRO(a1, sc1, sh1);
+        SN_MFMA1(a0, b0, w);
+        SN_MFMA1(a1, b1, x);
+        --remaining;
+        tile_done = (--c_left == 0);
+        more = remaining > 0;
+        const bool feed = more && !tile_done;
+        if (more) {
+            if (remaining > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SN_BARRIER();
+            SN_READ0P(0, OFF_NEXT, SOFF_NEXT);
+        }
+        if (feed) { issue_part(SLOT, 0); __builtin_amdgcn_sched_barrier(0); }
+        SN_MFMA1(a1, b1, y);
+        if (feed) { issue_part(SLOT, 1); __builtin_amdgcn_sched_barrier(0); }
+        SN_MFMA1(a1, b1, z);
+        if (feed) { issue_part(SLOT, 2); __builtin_amdgcn_sched_barrier(0); }
+        SN_MFMA1(a1, b1, w);
+        if (feed) { issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0); }
         } else {
         SN_WAIT0();
         SN_MFMA1(a0, b0, x);
@@ -399,7 +507,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
         if (feed) { issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0); }
         }
         if (tile_done) {
-            if (more) SN_WAIT0();                          // the next tile's first fragments: landed before the epilogue code
+            if (more) { if constexpr (PRO) SN_WAIT0P(); else SN_WAIT0(); }   // the next tile's first fragments: landed before the epilogue code
             else SN_BARRIER();                             // (otherwise the barrier above already retired slot SLOT)
             SN_STAMP(2);
             if constexpr (KG > 1) {
@@ -433,7 +541,10 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
                     conv_epilogue<1, 1, true>(acc, p, c_m0 + wm * 32, c_n0 + wn * 32, lane, 0,
                                               lds_base + (unsigned)(OFF + wave * SN_EPI_WAVE_BYTES));
                 }
-            } else
+            } else if constexpr (PRO)
+            conv_epilogue<1, 1, false, true>(acc, p, c_m0 + wm * 32, c_n0 + wn * 32, lane, c_z,
+                                             lds_base + (unsigned)(OFF + wave * SN_EPI_WAVE_BYTES), c_yoff, c_roff);
+            else
             conv_epilogue<1, 1>(acc, p, c_m0 + wm * 32, c_n0 + wn * 32, lane, c_z,
                                 lds_base + (unsigned)(OFF + wave * SN_EPI_WAVE_BYTES));
 #if RING_STAMP
@@ -466,4 +577,9 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 #undef SN_WAIT0
 #undef SN_WAIT1
 #undef SN_MFMA1
+#undef SN_READ0P
+#undef SN_READ1P
+#undef SN_WAIT0P
+#undef SN_WAIT1P
+#undef SN_PRO
 }

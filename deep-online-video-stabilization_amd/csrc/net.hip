@@ -637,15 +637,16 @@ const char* stabnet_prof_kind_name(int kind) {
                                              "conv_igemm_f32_pair_kernel<64, 64, 16, 32, 32, 1>", "conv_igemm_f32_pair_kernel<64, 64, 32, 32, 32, 1>"};
         return names[kind - PK_KERNEL_CONV_PAIR];
     }
-    if (kind == PK_KERNEL_CONV_KG) return "conv_ring_f32_kernel<0, 0, 3>";
-    if (kind == PK_KERNEL_CONV_KG + 1) return "conv_ring_f32_kernel<1, 0, 3>";
+    if (kind == PK_KERNEL_CONV_KG) return "conv_ring_f32_kernel<0, 0, 3, 0>";
+    if (kind == PK_KERNEL_CONV_KG + 1) return "conv_ring_f32_kernel<1, 0, 3, 0>";
+    if (kind == PK_KERNEL_CONV_KG + 2) return "conv_ring_f32_kernel<0, 0, 1, 1>";
     // names as rocprofv3 prints the template instantiation <MODE, BF16>
-    if (kind == PK_KERNEL_CONV_RING) return "conv_ring_f32_kernel<0, 0, 1>";
-    if (kind == PK_KERNEL_CONV_RING + 1) return "conv_ring_f32_kernel<1, 0, 1>";
-    if (kind == PK_KERNEL_CONV_RING + 2) return "conv_ring_f32_kernel<2, 0, 1>";
-    if (kind == PK_KERNEL_CONV_RING + 3) return "conv_ring_f32_kernel<0, 1, 1>";
-    if (kind == PK_KERNEL_CONV_RING + 4) return "conv_ring_f32_kernel<1, 1, 1>";
-    if (kind == PK_KERNEL_CONV_RING + 5) return "conv_ring_f32_kernel<2, 1, 1>";
+    if (kind == PK_KERNEL_CONV_RING) return "conv_ring_f32_kernel<0, 0, 1, 0>";
+    if (kind == PK_KERNEL_CONV_RING + 1) return "conv_ring_f32_kernel<1, 0, 1, 0>";
+    if (kind == PK_KERNEL_CONV_RING + 2) return "conv_ring_f32_kernel<2, 0, 1, 0>";
+    if (kind == PK_KERNEL_CONV_RING + 3) return "conv_ring_f32_kernel<0, 1, 1, 0>";
+    if (kind == PK_KERNEL_CONV_RING + 4) return "conv_ring_f32_kernel<1, 1, 1, 0>";
+    if (kind == PK_KERNEL_CONV_RING + 5) return "conv_ring_f32_kernel<2, 1, 1, 0>";
     if (kind >= PK_KERNEL_CONV_BASE && kind < PK_KERNEL_CONV_BASE + 72) {
         // names as rocprofv3 prints the template instantiation: <BM, BN, BK, WM, WN, MODE, NBUF, BF16>
         // (kind = base + MODE*6 + tile*2 + (BK==32) + 18 if NBUF == 1 + 36 if BF16, conv.hip)

@@ -16,6 +16,7 @@ ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os
 ap.add_argument("--reps", type=int, default=16)
 ap.add_argument("--gap-us", type=float, default=2.6, help="average launch gap charged to every extra (reduce) launch")
 ap.add_argument("--skip-train", action="store_true")
+ap.add_argument("--skip-infer", action="store_true")
 ap.add_argument("--infer-sizes", default="720x1280", help="comma list of HxW deploy workloads, e.g. 720x1280,1080x1920,288x512,256x256")
 ap.add_argument("--merge", action="store_true", help="keep the entries of the existing table for shapes not measured in this run")
 a = ap.parse_args()
@@ -25,6 +26,8 @@ CANDS = [1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20]
 
 def key_of(name, shp):
     M, N, K, _ = shp
+    if name.startswith("conv_ring_f32_kernel<0, 0, 1, 1>"):       # the fragment-prologue form runs the register-staged kernel's plans
+        return (M, N, K, 1, 0)
     if name.startswith("conv_ring_f32_kernel<0"):
         return (M, N, K, 1, 1)
     if name.startswith("conv_ring_f32_kernel<1"):
@@ -140,14 +143,17 @@ if a.merge and os.path.exists(a.out):
         v = [int(x) for x in m.groups()]
         if v[0] > 0:
             table[tuple(v[:5])] = v[5]
-for hw in a.infer_sizes.split(","):
+for hw in ([] if a.skip_infer else a.infer_sizes.split(",")):
     INFER_HW = tuple(int(v) for v in hw.split("x"))
     for k, v in tune(run_infer, "deploy %dx%d batch 1" % (INFER_HW[1], INFER_HW[0])).items():
         table[k] = v
 if not a.skip_train:
     t2 = tune(run_train, "train 8 x 288x512")
     for k, v in t2.items():
-        table.setdefault(k, v)
+        if a.skip_infer:
+            table[k] = v                 # a training-only run re-measures the training shapes: its results replace the merged entries
+        else:
+            table.setdefault(k, v)
 L.stabnet_conv_tuning_table_set(-1, 0, 0, 0, 0, 0)
 with open(a.out, "w") as f:
     f.write("// Measured split-K choices {M, Cout, K, KH, ring, splitk}; GENERATED by tools/tune_splitk.py on MI355X -- do not edit.\n")
