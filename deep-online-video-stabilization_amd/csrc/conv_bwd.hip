@@ -15,6 +15,7 @@
 #include "conv.h"
 #include "prof.h"
 #include "train_layers.h"
+#include "ring.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -34,6 +35,10 @@ struct WgradArgs {
     const float* in_shift;
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
     int M, K, rows_per_split;
+    int rowrun;              // 1 (general kernel only): x is the TIGHT zero-bordered image [N][H + 2 pad][W + 2 pad][Cin] (+ slack) the stem's
+                             //    ring kernel reads (ConvArgs::rowrun): k = kh * Rp + j, Rp = roundup(KW * Cin, 32), column j of filter row
+                             //    kh is float j of the run that starts at padded pixel (oy * stride + kh, ox * stride): no validity test,
+                             //    loads at 4-byte alignment; dw / slab are [Cout][KH][Rp] (columns j >= KW * Cin hold garbage: dropped later)
 };
 
 __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs p) {
@@ -56,9 +61,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs p) 
     const int lq = tid & 15, lr = tid >> 4;
     const int kcol = k0 + lq * 4;                          // this thread's k-columns: fixed tap and channels
     const bool k_ok = kcol < p.K;
-    const int tap = k_ok ? kcol / p.Cin : 0;
-    const int c_t = k_ok ? kcol - tap * p.Cin : 0;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int run = p.rowrun ? p.K / p.KH : p.Cin;         // row-run operand: a "tap" is a filter row, its "channels" the run
+    const int tap = k_ok ? kcol / run : 0;
+    const int c_t = k_ok ? kcol - tap * run : 0;
+    const int kh = p.rowrun ? tap : tap / p.KW, kw = p.rowrun ? 0 : tap - kh * p.KW;
+    const int Hp = p.H + 2 * p.pad, Wp = p.W + 2 * p.pad;       // (row-run operand only)
     const int ncol = n0 + lq * 4;
     const bool n_ok = ncol < p.Cout;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -87,10 +94,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs p) 
             const int m = m_cur + lr + 16 * t;
             const bool row_ok = m < m_end;
             const int iy = oy[t] * p.stride - p.pad + kh, ix = ox[t] * p.stride - p.pad + kw;
-            const bool a_ok = row_ok && k_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const bool a_ok = row_ok && k_ok && (p.rowrun || ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W));
             const unsigned yoff = (row_ok && n_ok) ? (unsigned)(m * p.Cout + ncol) : 0u;
-            const unsigned aoff = a_ok ? (unsigned)(((img[t] * p.H + iy) * p.W + ix) * p.Cin + c_t) : 0u;
+            const unsigned aoff = !a_ok ? 0u
+                                  : p.rowrun ? (unsigned)(((img[t] * Hp + oy[t] * p.stride + kh) * Wp + ox[t] * p.stride) * p.Cin + c_t)
+                                             : (unsigned)(((img[t] * p.H + iy) * p.W + ix) * p.Cin + c_t);
             ry[t] = *reinterpret_cast<const float4*>(pdy + yoff);
+            if (p.rowrun) {                                    // runs start at any 4-byte offset (Cin = 13)
+                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                const f4u v = *reinterpret_cast<const f4u*>(px + aoff);
+                ra[t] = make_float4(v.x, v.y, v.z, v.w);
+            } else
             ra[t] = *reinterpret_cast<const float4*>(px + aoff);
             ok |= ((row_ok && n_ok) ? 1u : 0u) << (2 * t);
             ok |= (a_ok ? 2u : 0u) << (2 * t);
@@ -427,7 +441,8 @@ int wgrad_reduce_flush(float* grads, WgradReduceTable& t, hipStream_t st) {
 // the reduce is launched here.
 int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* dw_base, long dw_off, const float* const* in_scale,
                    const float* const* in_shift, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                   float* slab_base, size_t* slab_cursor, size_t slab_capacity, WgradReduceTable* table, hipStream_t st, Prof* prof) {
+                   float* slab_base, size_t* slab_cursor, size_t slab_capacity, WgradReduceTable* table, hipStream_t st, Prof* prof,
+                   int rowrun) {
     WgradArgs a{};
     a.x = x[0]; a.dy = dy[0]; a.dw = dw_base + dw_off; a.in_scale = in_scale ? in_scale[0] : nullptr; a.in_shift = in_shift ? in_shift[0] : nullptr;
     if (T == 2) { a.x2 = x[1]; a.dy2 = dy[1]; a.in_scale2 = in_scale ? in_scale[1] : nullptr; a.in_shift2 = in_shift ? in_shift[1] : nullptr; }
@@ -435,10 +450,12 @@ int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* 
     a.Ho = (H + 2 * pad - KH) / stride + 1;
     a.Wo = (W + 2 * pad - KW) / stride + 1;
     a.M = N * a.Ho * a.Wo;
-    a.K = KH * KW * Cin;
+    a.K = rowrun ? KH * 32 * cdiv(KW * Cin, 32) : KH * KW * Cin;
+    a.rowrun = rowrun ? 1 : 0;
     SN_REQUIRE(T == 1 || T == 2, "wgrad: 1 or 2 towers");
-    SN_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "wgrad: channel counts must be multiples of 4");
-    SN_REQUIRE((long)a.M * Cout < (1L << 31) && (long)N * H * W * Cin < (1L << 31), "wgrad: tensors must have < 2^31 elements");
+    SN_REQUIRE((rowrun || Cin % 4 == 0) && Cout % 4 == 0, "wgrad: channel counts must be multiples of 4");
+    SN_REQUIRE((long)a.M * Cout < (1L << 31) && ((long)N * (H + 2 * pad) + 1) * (W + 2 * pad) * Cin < (1L << 31),
+               "wgrad: tensors must have < 2^31 elements");
     const int splits = wgrad_splits(Cout, a.K, a.M, &a.rows_per_split);
     a.splits_per_tower = splits;
     const int total = T * splits;
@@ -461,7 +478,7 @@ int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* 
     }
     const bool rec = prof != nullptr && prof->begin(st);
     static const bool fast_ok = getenv("STABNET_WGRAD_SAME") == nullptr || atoi(getenv("STABNET_WGRAD_SAME")) != 0;     // debug switch
-    const bool same = fast_ok && stride == 1 && a.Ho == H && a.Wo == W && KH == KW && (KH == 1 ? pad == 0 : (KH == 3 && pad == 1)) &&
+    const bool same = !rowrun && fast_ok && stride == 1 && a.Ho == H && a.Wo == W && KH == KW && (KH == 1 ? pad == 0 : (KH == 3 && pad == 1)) &&
                       a.M % 32 == 0 && Cout % 64 == 0 && a.K % 64 == 0 && 32 / W + 1 < H &&
                       ((long)a.M + 2L * W + 34) * Cin * 4 < (1L << 32) && ((long)32 * Cout + Cout) * 4 < (1L << 32);
     const dim3 grid(cdiv(Cout, 64), cdiv(a.K, 64), total);
@@ -479,6 +496,22 @@ int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* 
                        4.0 * T * ((double)a.M * Cout + (double)N * H * W * Cin + (double)a.K * Cout * splits), Cout, a.K, T * a.M, total);
     SN_LAUNCH_CHECK("conv_wgrad_f32_kernel");
     if (total > 1 && table == nullptr) return wgrad_reduce_flush(dw_base, local, st);
+    return STABNET_OK;
+}
+
+// dw [Cout][KH][KW][CinPad] += tmp [Cout][KH][Rp] (the row-run wgrad's layout: column kw * Cin + c of filter row kh; columns
+// beyond KW * Cin are not weights)
+__global__ __launch_bounds__(256) void wgrad_rowrun_scatter_kernel(const float* __restrict__ tmp, float* __restrict__ dw, int Cout,
+                                                                   int KH, int KW, int Cin, int CinPad, int Rp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cout * KH * KW * Cin) return;
+    const int c = i % Cin, kw = (i / Cin) % KW, kh = (i / (Cin * KW)) % KH, n = i / (Cin * KW * KH);
+    dw[(((size_t)n * KH + kh) * KW + kw) * CinPad + c] += tmp[((size_t)n * KH + kh) * Rp + kw * Cin + c];
+}
+int launch_wgrad_rowrun_scatter(const float* tmp, float* dw, int Cout, int KH, int KW, int Cin, int CinPad, hipStream_t st) {
+    const int Rp = 32 * cdiv(KW * Cin, 32);
+    wgrad_rowrun_scatter_kernel<<<cdiv((long)Cout * KH * KW * Cin, 256), 256, 0, st>>>(tmp, dw, Cout, KH, KW, Cin, CinPad, Rp);
+    SN_LAUNCH_CHECK("wgrad_rowrun_scatter_kernel");
     return STABNET_OK;
 }
 
@@ -606,6 +639,39 @@ int stabnet_conv2d_wgrad(const float* x, const float* dy, float* dw, const float
     size_t cursor = 0;
     return wgrad_launch(x, dy, dw, 0, in_scale, in_shift, N, H, W, Cin, Cout, KH, KW, stride, pad,
                         static_cast<float*>(workspace), &cursor, workspace_bytes / sizeof(float), nullptr, (hipStream_t)stream, nullptr);
+}
+
+/* The same gradient for a layer whose channel count is NOT a multiple of 4 (the 13-channel stem, train_bundle_nobm.py's
+ * x_tensor): x [N,H,W,Cin] tight, dw OHWI [Cout][KH][KW][CinPad] (ACCUMULATED into; the CinPad - Cin pad channels are left
+ * alone).  x is embedded into a zero-bordered image in `workspace` and read as filter-row runs (WgradArgs::rowrun), the way the
+ * training step's stem does it (there the bordered image is the forward's own operand). */
+static size_t rowrun_x_floats(int N, int H, int W, int Cin, int pad) { return (((size_t)N * (H + 2 * pad) + 1) * (W + 2 * pad) * Cin + 63) & ~(size_t)63; }
+size_t stabnet_conv2d_wgrad_rowrun_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1, Rp = 32 * cdiv(KW * Cin, 32);
+    return (rowrun_x_floats(N, H, W, Cin, pad) + (size_t)Cout * KH * Rp + wgrad_slab_floats(Cout, KH * Rp, N * Ho * Wo, 1)) * sizeof(float) + 16;
+}
+int stabnet_conv2d_wgrad_rowrun(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int CinPad, int Cout,
+                                int KH, int KW, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream) {
+    SN_REQUIRE(x && dy && dw && workspace, "conv2d_wgrad_rowrun: null pointer");
+    SN_REQUIRE(CinPad >= Cin && Cin >= 1 && pad >= 0 && (W + 2 * pad) * Cin >= 64, "conv2d_wgrad_rowrun: bad geometry");
+    SN_REQUIRE(workspace_bytes >= stabnet_conv2d_wgrad_rowrun_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad),
+               "conv2d_wgrad_rowrun: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int Rp = 32 * cdiv(KW * Cin, 32);
+    float* xb = static_cast<float*>(workspace);
+    float* tmp = xb + rowrun_x_floats(N, H, W, Cin, pad);
+    float* slabs = tmp + (size_t)Cout * KH * Rp;
+    int rc = launch_embed_border(x, N, H, W, Cin, pad, xb, st);
+    if (rc) return rc;
+    if (hipMemsetAsync(tmp, 0, (size_t)Cout * KH * Rp * sizeof(float), st) != hipSuccess) return STABNET_ERR_LAUNCH;
+    size_t cursor = 0;
+    const float* xs[1] = {xb};
+    const float* dys[1] = {dy};
+    rc = wgrad_launch_g(1, xs, dys, tmp, 0, nullptr, nullptr, N, H, W, Cin, Cout, KH, KW, stride, pad, slabs, &cursor,
+                        wgrad_slab_floats(Cout, KH * Rp, N * ((H + 2 * pad - KH) / stride + 1) * ((W + 2 * pad - KW) / stride + 1), 1),
+                        nullptr, st, nullptr, 1);
+    if (rc) return rc;
+    return launch_wgrad_rowrun_scatter(tmp, dw, Cout, KH, KW, Cin, CinPad, st);
 }
 
 /* d conv2d / d input: dx [N,H,W,Cin] (+ residual if given) from dy [N,Ho,Wo,Cout] and the forward weights

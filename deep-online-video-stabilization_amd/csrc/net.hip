@@ -103,7 +103,7 @@ struct BnInfo { long chan_off; int C; long tensor_off; long M; int H, W; };
 
 struct Net {
     int N, H, W, in_ch, in_ch_pad, n_theta, keep_all;
-    int stem_rowrun = 0, in_ch_act = 0;            // inference plans read the 13-channel stack directly (ring kernel MODE 2)
+    int stem_rowrun = 0, in_ch_act = 0;            // the stem reads the tight 13-channel stack directly (ring kernel MODE 2)
     int bf16_operands = 0;                        // secondary fast mode of the inference forward (stabnet_net_set_bf16_operands)
     size_t stem_w_floats = 0;
     struct MergeInfo { long off; int depth, dbn; long b_sc, bn1; };
@@ -212,7 +212,7 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
     net->in_ch_pad = (in_ch + 15) / 16 * 16;
     static const int want_rowrun = []() { const char* v = getenv("STABNET_STEM_ROWRUN"); return v ? atoi(v) : 1; }();
     static const int want_ring = []() { const char* v = getenv("STABNET_CONV_RING"); return v ? atoi(v) : 1; }();   // (debug switch)
-    net->stem_rowrun = (!keep_all && want_rowrun && want_ring && 7 * in_ch <= 128) ? 1 : 0;
+    net->stem_rowrun = (want_rowrun && want_ring && 7 * in_ch <= 128) ? 1 : 0;
     net->in_ch_act = net->stem_rowrun ? in_ch : net->in_ch_pad;
     net->stem_w_floats = net->stem_rowrun ? (size_t)64 * 7 * 32 * ((7 * in_ch + 31) / 32) : 0;
     Arena ar;
@@ -220,8 +220,8 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
     const std::string R = "resnet_v2_50/";
 
     // stem: conv2d_same(64, 7, stride 2) with bias, no BN/ReLU; then max_pool2d 3x3/2 SAME
-    // inference (row-run stem): the stack lives as a tight in_ch-channel image with a 3-pixel zero border (+ one slack row:
-    // the last run of the last row reads up to 31 floats past its taps); training: channels padded to 16, no border
+    // row-run stem: the stack lives as a tight in_ch-channel image with a 3-pixel zero border (+ one slack row: the last
+    // run of the last row reads up to 31 floats past its taps); STABNET_STEM_ROWRUN=0: channels padded to 16, no border
     const int border = net->stem_rowrun ? 3 : 0;
     TensorRef xin = net->stem_rowrun ? new_tensor(ar, N, H + 2 * border + 1, W + 2 * border, in_ch)
                                      : new_tensor(ar, N, H, W, net->in_ch_act);
@@ -894,6 +894,7 @@ struct TrainLayout {
     size_t fcx[4];                  // FC head inputs of the PAIR ([2N, dims[k]], tower 1's rows behind tower 0's), in tower 0's workspace
     size_t fcpart_floats;
     size_t splitk_bytes, slab_floats;
+    size_t stem_w, stem_dw;         // row-run stem: the weights re-laid-out for this step, and their gradient in that layout
 };
 
 static size_t rnd64(size_t n) { return (n + 63) & ~(size_t)63; }
@@ -920,7 +921,9 @@ static size_t net_slab_floats(const Net* net, int T, int s0, int s1) {
     for (int sg = s0; sg < s1; ++sg) {
         const int blk = 3 - sg;
         for (int ui = first[blk + 1] - 1; ui >= first[blk] && ui < (int)net->units.size(); --ui) n += unit_slab_floats(net->units[ui], T);
-        if (sg == kNumStagesFwd - 1) n += wgrad_slab_floats(64, 49 * net->in_ch_pad, net->t_c1.N * net->t_c1.H * net->t_c1.W, T);
+        if (sg == kNumStagesFwd - 1)
+            n += wgrad_slab_floats(64, net->stem_rowrun ? (int)(net->stem_w_floats / 64) : 49 * net->in_ch_pad,
+                                   net->t_c1.N * net->t_c1.H * net->t_c1.W, T);
     }
     return n;
 }
@@ -963,6 +966,7 @@ static TrainLayout train_layout(const Net* net) {
     // backward of both towers (their slabs of a layer are contiguous, in tower 0's workspace)
     L.slab_floats = net_slab_floats(net, 2, 0, kNumStagesFwd);
     L.slabs = take(L.slab_floats + 64);
+    L.stem_w = take(net->stem_w_floats); L.stem_dw = take(net->stem_w_floats);
     L.total = o;
     return L;
 }
@@ -1011,13 +1015,19 @@ static int run_forward_train(const Net* net, float* params, int T, const float* 
             const float* shift = w + L.bn_shift;
             switch (s.kind) {
                 case S_PAD:
-                    rc = launch_pad_channels(x[t], w + s.out_off, (long)s.N * s.H * s.W, s.C, net->in_ch_pad, st);
+                    if (net->stem_rowrun) {
+                        rc = launch_embed_border(x[t], s.N, s.H, s.W, s.C, 3, w + s.out_off, st);
+                        if (rc == STABNET_OK && t == 0)      // this step's stem weights in the row-run layout (both towers read them)
+                            rc = launch_stem_repack(params + net->w_stem, ws[0] + L.stem_w, 64, 7, 7, net->in_ch_pad, net->in_ch, st);
+                    } else {
+                        rc = launch_pad_channels(x[t], w + s.out_off, (long)s.N * s.H * s.W, s.C, net->in_ch_pad, st);
+                    }
                     break;
                 case S_CONV: {
                     const bool pair = T == 2 && s.pair_ok && pair_convs;
                     if (pair && t == 1) break;                         // launched with tower 0
                     ConvArgs a = pair ? s.conv_pair : s.conv;
-                    a.x = w + s.in_off; a.y = w + s.out_off; a.w = params + s.w_off;
+                    a.x = w + s.in_off; a.y = w + s.out_off; a.w = a.rowrun ? ws[0] + L.stem_w : params + s.w_off;
                     a.bias = s.b_off >= 0 ? params + s.b_off : nullptr;
                     a.residual = s.res_off >= 0 ? w + s.res_off : nullptr;
                     a.in_scale = s.bn_off >= 0 ? scale + s.bn_off : nullptr;
@@ -1106,14 +1116,15 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
     auto V = [](float* buf, size_t sz) { return [buf, sz](int t) -> float* { return buf + (size_t)t * sz; }; };
     auto CV = [](const float* buf, size_t sz) { return [buf, sz](int t) -> const float* { return buf + (size_t)t * sz; }; };
     // ONE wgrad launch per layer for both towers (grid.z = tower x split), slabs [tower][split] in tower 0's workspace
-    auto wgrad = [&](auto xin, auto dyin, long w_off, long bn, int H, int W, int Cin, int Cout, int K, int stride, int pad) -> int {
+    auto wgrad = [&](auto xin, auto dyin, long w_off, long bn, int H, int W, int Cin, int Cout, int K, int stride, int pad,
+                     int rowrun = 0) -> int {
         const float *xs[2], *dys[2], *sc[2], *sh[2];
         for (int t = 0; t < T; ++t) {
             xs[t] = xin(t); dys[t] = dyin(t);
             sc[t] = bn >= 0 ? tw[t].scale + bn : nullptr; sh[t] = bn >= 0 ? tw[t].shift + bn : nullptr;
         }
         return wgrad_launch_g(T, xs, dys, grads, w_off, bn >= 0 ? sc : nullptr, bn >= 0 ? sh : nullptr, N, H, W, Cin, Cout, K, K, stride,
-                              pad, tw[0].slabs, &cursor, L.slab_floats, &table, st, prof);
+                              pad, tw[0].slabs, &cursor, L.slab_floats, &table, st, prof, rowrun);
     };
     // BN + ReLU backward of both towers: one reduction launch, one finalize, one apply
     auto bn_bwd = [&](long bn, const TensorRef& xt, auto gin, auto addin, bool has_add, int add_stride, auto dxout) -> int {
@@ -1203,6 +1214,15 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
                                           st)) != 0) return rc;
         auto Xin = [&](int t) -> const float* { return tw[t].ws + net->t_xin.off; };
         if ((rc = bias_grad(CV(bGB, c1.size), (long)N * c1.H * c1.W, 64, net->b_stem)) != 0) return rc;
+        if (net->stem_rowrun) {
+            // the gradient comes out in the forward's row-run layout [64][7][roundup(7 * in_ch, 32)] (a scratch buffer the slab
+            // reduction accumulates into: addressed relative to `grads`, as every entry of the table is), then moves to OHWI
+            float* dw_rr = ws[0] + L.stem_dw;
+            if (hipMemsetAsync(dw_rr, 0, net->stem_w_floats * sizeof(float), st) != hipSuccess) return STABNET_ERR_LAUNCH;
+            if ((rc = wgrad(Xin, CV(bGB, c1.size), (long)(dw_rr - grads), -1, net->H, net->W, net->in_ch, 64, 7, 2, 3, 1)) != 0) return rc;
+            if ((rc = wgrad_reduce_flush(grads, table, st)) != 0) return rc;
+            return launch_wgrad_rowrun_scatter(dw_rr, grads + net->w_stem, 64, 7, 7, net->in_ch, net->in_ch_pad, st);
+        }
         if ((rc = wgrad(Xin, CV(bGB, c1.size), net->w_stem, -1, net->H, net->W, net->in_ch_pad, 64, 7, 2, 3)) != 0) return rc;
     }
     return wgrad_reduce_flush(grads, table, st);

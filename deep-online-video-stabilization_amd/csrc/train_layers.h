@@ -50,7 +50,11 @@ int wgrad_reduce_flush(float* grads, WgradReduceTable& t, hipStream_t st);
 // T towers (1 or 2) in ONE launch: grid.z = T * splits, slabs [tower][split]; the reduce adds them in that order into dw
 int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* dw_base, long dw_off, const float* const* in_scale,
                    const float* const* in_shift, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                   float* slab_base, size_t* slab_cursor, size_t slab_capacity, WgradReduceTable* table, hipStream_t st, Prof* prof);
+                   float* slab_base, size_t* slab_cursor, size_t slab_capacity, WgradReduceTable* table, hipStream_t st, Prof* prof,
+                   int rowrun = 0);
+// rowrun = 1 (the 13-channel stem): x is the zero-bordered tight image [N][H + 2 pad][W + 2 pad][Cin] (+ slack) of ConvArgs::rowrun and
+// the gradient comes out as [Cout][KH][roundup(KW * Cin, 32)]; launch_wgrad_rowrun_scatter adds it into OHWI [Cout][KH][KW][CinPad]
+int launch_wgrad_rowrun_scatter(const float* tmp, float* dw, int Cout, int KH, int KW, int Cin, int CinPad, hipStream_t st);
 int wgrad_launch(const float* x, const float* dy, float* dw_base, long dw_off, const float* in_scale, const float* in_shift,
                  int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* slab_base,
                  size_t* slab_cursor, size_t slab_capacity, WgradReduceTable* table, hipStream_t st, Prof* prof);

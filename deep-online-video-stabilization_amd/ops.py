@@ -58,6 +58,22 @@ def conv2d_wgrad(x, dy, w_shape, in_scale=None, in_shift=None, stride=1, pad=0, 
     return dw
 
 
+def conv2d_wgrad_rowrun(x, dy, w_shape, stride=1, pad=0, dw=None):
+    """dW (OHWI [Cout,KH,KW,CinPad], CinPad >= Cin) += d conv / d W for an input whose channel count is not a multiple of 4
+    (the 13-channel stem): the filter-row-run form the training step uses.  Pad channels of dw are not written."""
+    x = dev_f32(x, "x")
+    dy = dev_f32(dy, "dy")
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, CinPad = w_shape
+    if dw is None:
+        dw = torch.zeros(w_shape, dtype=torch.float32, device=x.device)
+    nbytes = _lib.lib().stabnet_conv2d_wgrad_rowrun_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    _lib.call("stabnet_conv2d_wgrad_rowrun", ptr(x), ptr(dy), ptr(dw), N, H, W, Cin, CinPad, Cout, KH, KW, stride, pad,
+              ptr(ws), nbytes, stream_ptr(x.device), device=x.device)
+    return dw
+
+
 def conv2d_dgrad(dy, w_ohwi, x_shape, stride=1, pad=0, residual=None):
     dy = dev_f32(dy, "dy")
     w = dev_f32(w_ohwi, "w")

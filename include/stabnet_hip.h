@@ -234,6 +234,13 @@ int stabnet_conv2d_wgrad(const float* x, const float* dy, float* dw, const float
                          int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* The same for a channel count that is not a multiple of 4 (the 13-channel stem input): x [N,H,W,Cin] tight,
+ * dw OHWI [Cout][KH][KW][CinPad] accumulated into (pad channels untouched).  x is embedded in a zero-bordered image inside
+ * `workspace` and read as runs of KW*Cin contiguous floats per filter row -- the operand layout of the training step's stem. */
+size_t stabnet_conv2d_wgrad_rowrun_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int stabnet_conv2d_wgrad_rowrun(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int CinPad, int Cout,
+                                int KH, int KW, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
+
 /* dx [N,H,W,Cin] = d conv2d / d input (+ residual if given, may alias dx) from dy [N,Ho,Wo,Cout] and the forward
  * weights (OHWI).  Cout % 16 == 0.  workspace: stabnet_conv2d_dgrad_workspace_bytes() (re-packed weights + split-K). */
 size_t stabnet_conv2d_dgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);

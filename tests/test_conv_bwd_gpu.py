@@ -56,3 +56,38 @@ def test_conv_backward(cuda, N, H, W, Cin, Cout, k, stride, pad, pro):
     # accumulation semantics of wgrad (second tower adds)
     dw2 = ops.conv2d_wgrad(f(x), f(g), (Cout, k, k, Cin), f(sc), f(sh), stride, pad, dw=dw.clone())
     assert torch.allclose(dw2, 2 * dw, rtol=1e-4, atol=1e-5 * float(dw.abs().max()))
+
+
+# the 13-channel stem's weight gradient on the tight zero-bordered operand (filter-row runs): several images (the border is per
+# image), odd sizes, another channel count / filter / stride, more than one tile of output channels
+ROWRUN_CASES = [
+    (1, 20, 28, 13, 16, 64, 7, 2, 3),
+    (3, 21, 27, 13, 16, 64, 7, 2, 3),
+    (2, 32, 64, 13, 16, 64, 7, 2, 3),
+    (2, 16, 24, 7, 8, 128, 3, 1, 1),
+    (2, 17, 40, 5, 5, 32, 5, 2, 2),
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,CinPad,Cout,k,stride,pad", ROWRUN_CASES)
+def test_wgrad_rowrun(cuda, N, H, W, Cin, CinPad, Cout, k, stride, pad):
+    from stabnet_amd import ops
+    rng = np.random.default_rng(N + H + Cin)
+    x = rng.standard_normal((N, H, W, Cin))
+    xt = torch.tensor(x, dtype=torch.float64)
+    wt = torch.zeros((Cout, k, k, Cin), dtype=torch.float64, requires_grad=True)
+    y = Fnn.conv2d(xt.permute(0, 3, 1, 2), wt.permute(0, 3, 1, 2), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    g = rng.standard_normal(tuple(y.shape))
+    (y * torch.tensor(g)).sum().backward()
+    want = wt.grad.numpy()
+    f = lambda v: torch.tensor(np.ascontiguousarray(v), dtype=torch.float32, device=cuda)
+    seed = f(rng.standard_normal((Cout, k, k, CinPad)))          # accumulated into; pad channels stay what they were
+    dw = ops.conv2d_wgrad_rowrun(f(x), f(g), (Cout, k, k, CinPad), stride, pad, dw=seed.clone())
+    got = (dw - seed).cpu().numpy()
+    assert np.abs(got[..., :Cin] - want).max() <= 2e-5 * np.abs(want).max() * np.sqrt(N * H * W / 64 + 1) + 1e-6
+    assert np.array_equal(dw[..., Cin:].cpu().numpy(), seed[..., Cin:].cpu().numpy())
+    # against the library's general kernel on the channel-padded input: same products, another summation order
+    xp = np.zeros((N, H, W, 16), dtype=np.float32)
+    xp[..., :Cin] = x
+    ref = ops.conv2d_wgrad(f(xp), f(g), (Cout, k, k, 16), None, None, stride, pad).cpu().numpy()[..., :Cin]
+    assert np.abs(got[..., :Cin] - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-6
