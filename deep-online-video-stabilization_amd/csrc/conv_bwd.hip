@@ -35,6 +35,8 @@ struct WgradArgs {
     const float* in_shift;
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
     int M, K, rows_per_split;
+    float* bias_slab;        // "same" 1x1 kernel with BIAS: column sums of dY (the bias gradient of the layer) per (tower, split):
+    float *dbias, *dbias2;   //    bias_slab [T * splits][Cout] (reduced with the weight slabs), or += into dbias (and dbias2) when nothing is split
     int rowrun;              // 1 (general kernel only): x is the TIGHT zero-bordered image [N][H + 2 pad][W + 2 pad][Cin] (+ slack) the stem's
                              //    ring kernel reads (ConvArgs::rowrun): k = kh * Rp + j, Rp = roundup(KW * Cin, 32), column j of filter row
                              //    kh is float j of the run that starts at padded pixel (oy * stride + kh, ox * stride): no validity test,
@@ -178,7 +180,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs p) 
 // coordinates with divisions-by-loop and 64-bit addresses every step: 103 VALU instructions per 16 MFMAs, and on gfx950 every
 // VALU instruction costs ~3 cycles of f32-MFMA issue.  Requirements (host-checked): stride 1, Ho == H,
 // Wo == W, M % 32 == 0, Cout % 64 == 0, K % 64 == 0, Cin % 4 == 0, 32 / W + 1 < H.
-template <int K3, int PRO /* BN + ReLU prologue on x */>
+// BIAS: the workgroups of k-tile 0 also sum their dY tiles over the pixels (per thread over its rows, then the 16 row-threads of
+// a column quad in a fixed order): the bias gradient of the layer comes out of the pass that reads dY anyway.
+template <int K3, int PRO /* BN + ReLU prologue on x */, int BIAS = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_same_f32_kernel(const WgradArgs p) {
     constexpr int BR = 32, BT = 64;
     __shared__ __attribute__((aligned(16))) float sY[2][BR][BT];
@@ -270,12 +274,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_same_f32_kernel(const WgradArg
         if (K3 && !(OK)) a_ = make_float4(0.f, 0.f, 0.f, 0.f);                                    \
         *reinterpret_cast<float4*>(&sY[BUF][ROW][lq * 4]) = (RY);                                 \
         *reinterpret_cast<float4*>(&sA[BUF][ROW][lq * 4]) = a_;                                   \
+        if (BIAS && do_bias) { bsum.x += (RY).x; bsum.y += (RY).y; bsum.z += (RY).z; bsum.w += (RY).w; } \
     } while (0)
 #define SN_WG_STORE_TILES(BUF)                                  \
     do {                                                        \
         SN_WG_STORE_ROW(ry0, ra0, ok0, lr, BUF);                \
         SN_WG_STORE_ROW(ry1, ra1, ok1, lr + 16, BUF);           \
     } while (0)
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_bias = BIAS && blockIdx.y == 0;
 
     f32x16w acc;
 #pragma unroll
@@ -318,6 +325,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_same_f32_kernel(const WgradArg
         if (p.slab != nullptr) p.slab[((size_t)blockIdx.z * p.Cout + n) * p.K + k] = acc[r];
         else p.dw[(size_t)n * p.K + k] += acc[r];
     }
+    if (BIAS && do_bias) {
+        // rows lr = 4 * wave + (lane >> 4): the wave's four row-threads of a column quad by two exchanges, the four waves through
+        // LDS (the tiles are dead: the loop ended on a barrier), added in wave order
+        float* red = &sY[0][0][0];                              // [4 waves][64 columns]
+        float v[4] = {bsum.x, bsum.y, bsum.z, bsum.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] += __shfl_xor(v[j], 16, 64);
+            v[j] += __shfl_xor(v[j], 32, 64);
+        }
+        if (lane < 16) *reinterpret_cast<float4*>(red + wave * 64 + lq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        __syncthreads();
+        if (tid < 64) {
+            const float t = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+            if (p.bias_slab != nullptr) p.bias_slab[(size_t)blockIdx.z * p.Cout + n0 + tid] = t;
+            else {
+                p.dbias[n0 + tid] += t;
+                if (p.dbias2 != nullptr) p.dbias2[n0 + tid] += t;
+            }
+        }
+    }
 }
 
 // Wt[ci][kh][kw][co] = W[co][KH-1-kh][KW-1-kw][ci]  : the weights of the dgrad convolution (OHWI in, OHWI out)
@@ -349,9 +377,26 @@ int wgrad_splits(int Cout, int K, int M, int* rows_per_split) {
     return cdiv(M, rps);
 }
 // slab floats one launch over T towers needs (none when a single block owns every element: T * splits == 1)
-size_t wgrad_slab_floats(int Cout, int K, int M, int T) {
+size_t wgrad_slab_floats(int Cout, int K, int M, int T, int with_bias) {
     const int s = T * wgrad_splits(Cout, K, M, nullptr);
-    return s > 1 ? (size_t)s * Cout * K : 0;
+    return s > 1 ? (size_t)s * Cout * (K + (with_bias ? 1 : 0)) : 0;
+}
+
+static bool wgrad_same_geometry(const WgradArgs& a, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    static const bool fast_ok = getenv("STABNET_WGRAD_SAME") == nullptr || atoi(getenv("STABNET_WGRAD_SAME")) != 0;     // debug switch
+    return fast_ok && stride == 1 && a.Ho == H && a.Wo == W && KH == KW && (KH == 1 ? pad == 0 : (KH == 3 && pad == 1)) &&
+           a.M % 32 == 0 && Cout % 64 == 0 && a.K % 64 == 0 && 32 / W + 1 < H &&
+           ((long)a.M + 2L * W + 34) * Cin * 4 < (1L << 32) && ((long)32 * Cout + Cout) * 4 < (1L << 32);
+}
+// 1 if wgrad_launch_g can also produce the layer's bias gradient (1x1 layers on the "same" kernel)
+int wgrad_bias_fusable(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    static const bool on = getenv("STABNET_WGRAD_BIAS") == nullptr || atoi(getenv("STABNET_WGRAD_BIAS")) != 0;          // debug switch
+    WgradArgs a{};
+    a.Ho = (H + 2 * pad - KH) / stride + 1;
+    a.Wo = (W + 2 * pad - KW) / stride + 1;
+    a.M = N * a.Ho * a.Wo;
+    a.K = KH * KW * Cin;
+    return on && KH == 1 && Cin % 4 == 0 && Cout % 256 == 0 && wgrad_same_geometry(a, H, W, Cin, Cout, KH, KW, stride, pad);
 }
 
 // dw += sum_z slab[0][z] (+ sum_z slab[1][z]) (z ascending, tower 0 then tower 1) for every entry of the table; one float4 per thread.
@@ -442,7 +487,7 @@ int wgrad_reduce_flush(float* grads, WgradReduceTable& t, hipStream_t st) {
 int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* dw_base, long dw_off, const float* const* in_scale,
                    const float* const* in_shift, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                    float* slab_base, size_t* slab_cursor, size_t slab_capacity, WgradReduceTable* table, hipStream_t st, Prof* prof,
-                   int rowrun) {
+                   int rowrun, long bias_off, long bias_off2) {
     WgradArgs a{};
     a.x = x[0]; a.dy = dy[0]; a.dw = dw_base + dw_off; a.in_scale = in_scale ? in_scale[0] : nullptr; a.in_shift = in_shift ? in_shift[0] : nullptr;
     if (T == 2) { a.x2 = x[1]; a.dy2 = dy[1]; a.in_scale2 = in_scale ? in_scale[1] : nullptr; a.in_shift2 = in_shift ? in_shift[1] : nullptr; }
@@ -460,6 +505,11 @@ int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* 
     a.splits_per_tower = splits;
     const int total = T * splits;
     const size_t elems = (size_t)Cout * a.K;
+    const bool bias = bias_off >= 0;
+    SN_REQUIRE(!bias || (!rowrun && wgrad_bias_fusable(N, H, W, Cin, Cout, KH, KW, stride, pad)), "wgrad: this layer cannot carry its bias gradient");
+    SN_REQUIRE(bias || bias_off2 < 0, "wgrad: second bias without a first");
+    a.dbias = bias ? dw_base + bias_off : nullptr;
+    a.dbias2 = bias_off2 >= 0 ? dw_base + bias_off2 : nullptr;
     WgradReduceTable local{};
     if (total > 1) {
         SN_REQUIRE(slab_base != nullptr && slab_cursor != nullptr, "wgrad: %d splits need a slab workspace", total);
@@ -475,15 +525,30 @@ int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* 
         t->prefix[t->n + 1] = t->prefix[t->n] + (long)(elems / 4);
         ++t->n;
         *slab_cursor += (size_t)total * elems;
+        if (bias) {                                          // [tower][split][Cout] column sums of dY, reduced like a weight slab
+            SN_REQUIRE(*slab_cursor + (size_t)total * Cout <= slab_capacity, "wgrad: slab workspace overrun (bias sums)");
+            a.bias_slab = slab_base + *slab_cursor;
+            const long offs[2] = {bias_off, bias_off2};
+            for (int i = 0; i < 2 && offs[i] >= 0; ++i) {
+                if (t->n == WGRAD_TABLE_MAX) {
+                    int rc = wgrad_reduce_flush(dw_base, *t, st);
+                    if (rc) return rc;
+                }
+                t->e[t->n] = {offs[i], (long)Cout, {a.bias_slab, nullptr}, total};
+                t->prefix[t->n + 1] = t->prefix[t->n] + (long)(Cout / 4);
+                ++t->n;
+            }
+            *slab_cursor += (size_t)total * Cout;
+        }
     }
     const bool rec = prof != nullptr && prof->begin(st);
-    static const bool fast_ok = getenv("STABNET_WGRAD_SAME") == nullptr || atoi(getenv("STABNET_WGRAD_SAME")) != 0;     // debug switch
-    const bool same = !rowrun && fast_ok && stride == 1 && a.Ho == H && a.Wo == W && KH == KW && (KH == 1 ? pad == 0 : (KH == 3 && pad == 1)) &&
-                      a.M % 32 == 0 && Cout % 64 == 0 && a.K % 64 == 0 && 32 / W + 1 < H &&
-                      ((long)a.M + 2L * W + 34) * Cin * 4 < (1L << 32) && ((long)32 * Cout + Cout) * 4 < (1L << 32);
+    const bool same = !rowrun && wgrad_same_geometry(a, H, W, Cin, Cout, KH, KW, stride, pad);
     const dim3 grid(cdiv(Cout, 64), cdiv(a.K, 64), total);
     const bool pro = a.in_scale != nullptr;
-    if (same && KH == 1) {
+    if (same && KH == 1 && bias) {
+        if (pro) conv_wgrad_same_f32_kernel<0, 1, 1><<<grid, 256, 0, st>>>(a);
+        else conv_wgrad_same_f32_kernel<0, 0, 1><<<grid, 256, 0, st>>>(a);
+    } else if (same && KH == 1) {
         if (pro) conv_wgrad_same_f32_kernel<0, 1><<<grid, 256, 0, st>>>(a);
         else conv_wgrad_same_f32_kernel<0, 0><<<grid, 256, 0, st>>>(a);
     } else if (same) {
@@ -639,6 +704,29 @@ int stabnet_conv2d_wgrad(const float* x, const float* dy, float* dw, const float
     size_t cursor = 0;
     return wgrad_launch(x, dy, dw, 0, in_scale, in_shift, N, H, W, Cin, Cout, KH, KW, stride, pad,
                         static_cast<float*>(workspace), &cursor, workspace_bytes / sizeof(float), nullptr, (hipStream_t)stream, nullptr);
+}
+
+/* 1x1 stride-1 layers with Cout % 256 == 0 (the unit-closing convolutions of the regressor): dW as above AND the bias gradient
+ * d_bias [Cout] += column sums of dy, from the same pass over dy (the training step's form).  STABNET_ERR_BAD_ARG for a
+ * geometry the stride-1 kernel does not take. */
+size_t stabnet_conv2d_wgrad_bias_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+    return wgrad_slab_floats(Cout, Cin, N * H * W, 1, 1) * sizeof(float) + 16;
+}
+int stabnet_conv2d_wgrad_bias(const float* x, const float* dy, float* dw, float* d_bias, const float* in_scale, const float* in_shift,
+                              int N, int H, int W, int Cin, int Cout, void* workspace, size_t workspace_bytes, void* stream) {
+    SN_REQUIRE(x && dy && dw && d_bias, "conv2d_wgrad_bias: null pointer");
+    SN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv2d_wgrad_bias: in_scale and in_shift go together");
+    SN_REQUIRE(workspace != nullptr && workspace_bytes >= stabnet_conv2d_wgrad_bias_workspace_bytes(N, H, W, Cin, Cout),
+               "conv2d_wgrad_bias: workspace too small");
+    size_t cursor = 0;
+    const float* xs[1] = {x};
+    const float* dys[1] = {dy};
+    const float* sc[1] = {in_scale};
+    const float* sh[1] = {in_shift};
+    // (one base for both gradients: the bias is addressed relative to dw, as the training step addresses its flat gradient buffer)
+    return wgrad_launch_g(1, xs, dys, dw, 0, in_scale ? sc : nullptr, in_scale ? sh : nullptr, N, H, W, Cin, Cout, 1, 1, 1, 0,
+                          static_cast<float*>(workspace), &cursor, workspace_bytes / sizeof(float), nullptr, (hipStream_t)stream, nullptr,
+                          0, (long)(d_bias - dw), -1);
 }
 
 /* The same gradient for a layer whose channel count is NOT a multiple of 4 (the 13-channel stem, train_bundle_nobm.py's

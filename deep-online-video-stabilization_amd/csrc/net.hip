@@ -910,7 +910,7 @@ static ConvArgs dgrad_args(int N, int H, int W, int Cin, int Cout, int KH, int s
 // slab floats the wgrad launches of backward stages [s0, s1) need for T towers (stage order: see run_backward_stage)
 static const int kNumStagesFwd = 4;
 static size_t unit_slab_floats(const UnitInfo& u, int T) {
-    size_t n = wgrad_slab_floats(u.depth, u.dbn, u.out.N * u.out.H * u.out.W, T) + wgrad_slab_floats(u.dbn, 9 * u.dbn, u.r2.N * u.r2.H * u.r2.W, T) +
+    size_t n = wgrad_slab_floats(u.depth, u.dbn, u.out.N * u.out.H * u.out.W, T, 1) + wgrad_slab_floats(u.dbn, 9 * u.dbn, u.r2.N * u.r2.H * u.r2.W, T) +
                wgrad_slab_floats(u.dbn, u.cin, u.x.N * u.x.H * u.x.W, T);
     if (u.proj) n += wgrad_slab_floats(u.depth, u.cin, u.x.N * u.x.H * u.x.W, T);
     return n;
@@ -1117,14 +1117,14 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
     auto CV = [](const float* buf, size_t sz) { return [buf, sz](int t) -> const float* { return buf + (size_t)t * sz; }; };
     // ONE wgrad launch per layer for both towers (grid.z = tower x split), slabs [tower][split] in tower 0's workspace
     auto wgrad = [&](auto xin, auto dyin, long w_off, long bn, int H, int W, int Cin, int Cout, int K, int stride, int pad,
-                     int rowrun = 0) -> int {
+                     int rowrun = 0, long b_off = -1, long b_off2 = -1) -> int {
         const float *xs[2], *dys[2], *sc[2], *sh[2];
         for (int t = 0; t < T; ++t) {
             xs[t] = xin(t); dys[t] = dyin(t);
             sc[t] = bn >= 0 ? tw[t].scale + bn : nullptr; sh[t] = bn >= 0 ? tw[t].shift + bn : nullptr;
         }
         return wgrad_launch_g(T, xs, dys, grads, w_off, bn >= 0 ? sc : nullptr, bn >= 0 ? sh : nullptr, N, H, W, Cin, Cout, K, K, stride,
-                              pad, tw[0].slabs, &cursor, L.slab_floats, &table, st, prof, rowrun);
+                              pad, tw[0].slabs, &cursor, L.slab_floats, &table, st, prof, rowrun, b_off, b_off2);
     };
     // BN + ReLU backward of both towers: one reduction launch, one finalize, one apply
     auto bn_bwd = [&](long bn, const TensorRef& xt, auto gin, auto addin, bool has_add, int add_stride, auto dxout) -> int {
@@ -1184,8 +1184,11 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
         auto X = [&](long off) { return [&, off](int t) -> const float* { return tw[t].ws + off; }; };
         // conv3 (1x1, bias) : input relu(bn2(r2))
         // (the projection shortcut's bias receives the same column sums of G: one reduction for both)
-        if ((rc = bias_grad(CV(bGA, so), Mo, u.depth, u.b3, u.proj ? u.b_sc : -1)) != 0) return rc;
-        if ((rc = wgrad(X(u.r2.off), CV(bGA, so), u.w3, u.bn2, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0)) != 0) return rc;
+        // -- and where conv3's wgrad runs on the stride-1 kernel (every unit of the regressor) they come out of ITS pass over G
+        const bool bias_in_wgrad = wgrad_bias_fusable(N, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 1, 0) != 0;
+        if (!bias_in_wgrad && (rc = bias_grad(CV(bGA, so), Mo, u.depth, u.b3, u.proj ? u.b_sc : -1)) != 0) return rc;
+        if ((rc = wgrad(X(u.r2.off), CV(bGA, so), u.w3, u.bn2, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0, 0, bias_in_wgrad ? u.b3 : -1,
+                        bias_in_wgrad && u.proj ? u.b_sc : -1)) != 0) return rc;
         if ((rc = dgrad(bGA, net->pack_w3[ui], bT1, nullptr, u.r2.H, u.r2.W, u.dbn, u.depth, 1, 1, 0)) != 0) return rc;
         if ((rc = bn_bwd(u.bn2, u.r2, CV(bT1, sr2), none, false, 1, V(bT1, sr2))) != 0) return rc;             // T1 = d r2
         // conv2 (3x3, stride) : input relu(bn1(r1))

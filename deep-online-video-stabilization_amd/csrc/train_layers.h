@@ -45,13 +45,17 @@ int launch_adam(float* w, const float* g, const float* g2, float* m, float* v, l
 struct WgradReduceEntry { long dw_off, elems; const float* slab[2]; int splits; };   // slab[t]: tower t's [splits][elems] partials (or null)
 struct WgradReduceTable { WgradReduceEntry e[WGRAD_TABLE_MAX]; long prefix[WGRAD_TABLE_MAX + 1]; int n; };
 int wgrad_splits(int Cout, int K, int M, int* rows_per_split);
-size_t wgrad_slab_floats(int Cout, int K, int M, int T);
+size_t wgrad_slab_floats(int Cout, int K, int M, int T, int with_bias = 0);
 int wgrad_reduce_flush(float* grads, WgradReduceTable& t, hipStream_t st);
 // T towers (1 or 2) in ONE launch: grid.z = T * splits, slabs [tower][split]; the reduce adds them in that order into dw
 int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* dw_base, long dw_off, const float* const* in_scale,
                    const float* const* in_shift, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                    float* slab_base, size_t* slab_cursor, size_t slab_capacity, WgradReduceTable* table, hipStream_t st, Prof* prof,
-                   int rowrun = 0);
+                   int rowrun = 0, long bias_off = -1, long bias_off2 = -1);
+// bias_off >= 0 (only where wgrad_bias_fusable(): 1x1 layers on the stride-1 kernel, Cout % 256 == 0): the launch also leaves the
+// column sums of dy -- the gradient of the layer's bias -- at dw_base + bias_off (and + bias_off2: a second bias with the same
+// gradient, the projection shortcut's), through the same slab reduction.
+int wgrad_bias_fusable(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 // rowrun = 1 (the 13-channel stem): x is the zero-bordered tight image [N][H + 2 pad][W + 2 pad][Cin] (+ slack) of ConvArgs::rowrun and
 // the gradient comes out as [Cout][KH][roundup(KW * Cin, 32)]; launch_wgrad_rowrun_scatter adds it into OHWI [Cout][KH][KW][CinPad]
 int launch_wgrad_rowrun_scatter(const float* tmp, float* dw, int Cout, int KH, int KW, int Cin, int CinPad, hipStream_t st);

@@ -58,6 +58,25 @@ def conv2d_wgrad(x, dy, w_shape, in_scale=None, in_shift=None, stride=1, pad=0, 
     return dw
 
 
+def conv2d_wgrad_bias(x, dy, w_shape, in_scale=None, in_shift=None, dw=None, db=None):
+    """1x1 layers: (dW, d_bias) += gradients, the bias sums taken from the wgrad kernel's own pass over dy."""
+    x = dev_f32(x, "x")
+    dy = dev_f32(dy, "dy")
+    N, H, W, Cin = x.shape
+    Cout = w_shape[0]
+    assert tuple(w_shape[1:]) == (1, 1, Cin)
+    buf = torch.zeros(Cout * Cin + Cout, dtype=torch.float32, device=x.device)      # one allocation: d_bias sits behind dW
+    if dw is not None:
+        buf[:Cout * Cin] = dw.reshape(-1)
+    if db is not None:
+        buf[Cout * Cin:] = db
+    nbytes = _lib.lib().stabnet_conv2d_wgrad_bias_workspace_bytes(N, H, W, Cin, Cout)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    _lib.call("stabnet_conv2d_wgrad_bias", ptr(x), ptr(dy), buf.data_ptr(), buf.data_ptr() + 4 * Cout * Cin, ptr(in_scale), ptr(in_shift),
+              N, H, W, Cin, Cout, ptr(ws), nbytes, stream_ptr(x.device), device=x.device)
+    return buf[:Cout * Cin].reshape(w_shape), buf[Cout * Cin:]
+
+
 def conv2d_wgrad_rowrun(x, dy, w_shape, stride=1, pad=0, dw=None):
     """dW (OHWI [Cout,KH,KW,CinPad], CinPad >= Cin) += d conv / d W for an input whose channel count is not a multiple of 4
     (the 13-channel stem): the filter-row-run form the training step uses.  Pad channels of dw are not written."""

@@ -234,6 +234,12 @@ int stabnet_conv2d_wgrad(const float* x, const float* dy, float* dw, const float
                          int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* 1x1 stride-1 layers with Cout % 256 == 0: dW as above and d_bias [Cout] += column sums of dy from the same pass over dy
+ * (what the training step does for the unit-closing convolutions).  Other geometries: STABNET_ERR_BAD_ARG. */
+size_t stabnet_conv2d_wgrad_bias_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int stabnet_conv2d_wgrad_bias(const float* x, const float* dy, float* dw, float* d_bias, const float* in_scale, const float* in_shift,
+                              int N, int H, int W, int Cin, int Cout, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same for a channel count that is not a multiple of 4 (the 13-channel stem input): x [N,H,W,Cin] tight,
  * dw OHWI [Cout][KH][KW][CinPad] accumulated into (pad channels untouched).  x is embedded in a zero-bordered image inside
  * `workspace` and read as runs of KW*Cin contiguous floats per filter row -- the operand layout of the training step's stem. */

@@ -91,3 +91,32 @@ def test_wgrad_rowrun(cuda, N, H, W, Cin, CinPad, Cout, k, stride, pad):
     xp[..., :Cin] = x
     ref = ops.conv2d_wgrad(f(xp), f(g), (Cout, k, k, 16), None, None, stride, pad).cpu().numpy()[..., :Cin]
     assert np.abs(got[..., :Cin] - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-6
+
+
+# the unit-closing 1x1 layers: the bias gradient rides in the wgrad launch (column sums of dy per pixel split, reduced with the slabs)
+@pytest.mark.parametrize("N,H,W,Cin,Cout,pro", [(2, 16, 32, 64, 256, True), (2, 9, 16, 128, 512, True), (3, 8, 8, 512, 2048, False),
+                                                (2, 72, 128, 64, 256, True)])
+def test_wgrad_with_bias(cuda, N, H, W, Cin, Cout, pro):
+    from stabnet_amd import ops
+    rng = np.random.default_rng(Cin + Cout + N)
+    x = rng.standard_normal((N, H, W, Cin))
+    g = rng.standard_normal((N, H, W, Cout))
+    sc = rng.uniform(0.5, 1.5, Cin) if pro else None
+    sh = rng.standard_normal(Cin) * 0.3 if pro else None
+    f = lambda v: None if v is None else torch.tensor(np.ascontiguousarray(v), dtype=torch.float32, device=cuda)
+    dw0 = f(rng.standard_normal((Cout, 1, 1, Cin)))
+    db0 = f(rng.standard_normal(Cout))
+    dw, db = ops.conv2d_wgrad_bias(f(x), f(g), (Cout, 1, 1, Cin), f(sc), f(sh), dw=dw0, db=db0)
+    ref = ops.conv2d_wgrad(f(x), f(g), (Cout, 1, 1, Cin), f(sc), f(sh), 1, 0, dw=dw0.clone())
+    assert torch.equal(dw, ref)                                 # the weight gradient is the plain launch's, bit for bit
+    want = g.reshape(-1, Cout).sum(0)
+    got = (db - db0).cpu().numpy()
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max() * np.sqrt(N * H * W / 64 + 1)
+
+
+def test_wgrad_with_bias_refuses_other_geometries(cuda):
+    from stabnet_amd import ops, _lib
+    x = torch.zeros((1, 8, 8, 64), device=cuda)
+    g = torch.zeros((1, 8, 8, 64), device=cuda)
+    with pytest.raises(_lib.StabnetError):
+        ops.conv2d_wgrad_bias(x, g, (64, 1, 1, 64))             # Cout % 256 != 0
