@@ -179,21 +179,29 @@ __global__ __launch_bounds__(256) void fc_lds_kernel(const float* __restrict__ x
                                                      int relu) {
     extern __shared__ __attribute__((aligned(16))) float xs[];          // [M][K]
     const int tid = threadIdx.x, lane = tid & 63;
+    const int waves = gridDim.x * 4;
+    int n = blockIdx.x * 4 + (tid >> 6);
+    // the first weight row's loads go out BEFORE the activations are staged (the weights are the kernel's only HBM stream), and
+    // every later row's before the products of the row in front of it
+    float4 wv[8], wn[8];
+    auto load_row = [&](float4 (&dst)[8], int row, int kb) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kb + j * 256 + lane * 4;
+            dst[j] = (row < Nout && k < K) ? *reinterpret_cast<const float4*>(w + (size_t)row * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load_row(wv, n, 0);
     for (int i = tid * 4; i < M * K; i += 256 * 4) *reinterpret_cast<float4*>(xs + i) = *reinterpret_cast<const float4*>(x + i);
     __syncthreads();
-    const int waves = gridDim.x * 4;
-    for (int n = blockIdx.x * 4 + (tid >> 6); n < Nout; n += waves) {
+    for (; n < Nout; n += waves) {
         float acc[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        const float* wr = w + (size_t)n * K;
-        for (int kb = 0; kb < K; kb += 8 * 256) {          // eight 16-B loads of the weight row in flight per lane, then the products
-            float4 wv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = kb + j * 256 + lane * 4;
-                wv[j] = (k < K) ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+        for (int kb = 0; kb < K; kb += 8 * 256) {
+            // next chunk of this row, or the first chunk of the wave's next row, while this chunk is multiplied
+            const bool last = kb + 8 * 256 >= K;
+            load_row(wn, last ? n + waves : n, last ? 0 : kb + 8 * 256);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = kb + j * 256 + lane * 4;
@@ -207,6 +215,8 @@ __global__ __launch_bounds__(256) void fc_lds_kernel(const float* __restrict__ x
                     }
                 }
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = wn[j];
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {

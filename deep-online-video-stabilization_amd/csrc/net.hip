@@ -945,7 +945,7 @@ static TrainLayout train_layout(const Net* net) {
         red = std::max(red, col_reduce_workspace_floats((long)u.out.N * u.out.H * u.out.W, u.depth, 2));
     red = std::max(red, col_reduce_workspace_floats((long)net->t_c1.N * net->t_c1.H * net->t_c1.W, 64, 2));
     L.partial = take(red);
-    L.fcpart_floats = (size_t)64 * 2 * net->N * 2048;        // fc_bwd_x partials: (Nout/32 <= 64 splits) x 2N x K
+    L.fcpart_floats = (size_t)64 * 2 * net->N * 2048;        // fc_bwd_x partials: (<= 64 splits) x 2N x K (train_layers.hip picks ~256 workgroups: 8..16 splits here)
     L.fcpart = take(L.fcpart_floats);
     L.coef = take(3 * std::max<size_t>(net->max_c, 2048));
     L.wt = take((size_t)net->packs.prefix[net->packs.n]);
