@@ -235,15 +235,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnApply A, int 
 __global__ __launch_bounds__(256) void max_pool_bwd_kernel(const unsigned char* __restrict__ argmax, const float* __restrict__ dy,
                                                            float* __restrict__ dx, int N, int H, int W, int C, int Ho,
                                                            int Wo, int k, int stride, int pt, int pl) {
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;          // one thread per (input pixel, 4 channels)
-    const int c4n = C / 4;
-    const long total = (long)N * H * W * c4n;
-    if (q >= total) return;
+    const unsigned q = blockIdx.x * 256u + threadIdx.x;           // one thread per (input pixel, 4 channels); < 2^32 (host-checked)
+    const unsigned c4n = (unsigned)C / 4u;
+    if (q >= (unsigned)N * H * W * c4n) return;
     const int c = (int)(q % c4n) * 4;
-    long r = q / c4n;
-    const int ix = (int)(r % W); r /= W;
-    const int iy = (int)(r % H);
-    const int n = (int)(r / H);
+    unsigned r = q / c4n;
+    const int ix = (int)(r % (unsigned)W); r /= (unsigned)W;
+    const int iy = (int)(r % (unsigned)H);
+    const int n = (int)(r / (unsigned)H);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int oy_lo = max(0, (iy + pt - k + stride) / stride), oy_hi = min(Ho - 1, (iy + pt) / stride);
     const int ox_lo = max(0, (ix + pl - k + stride) / stride), ox_hi = min(Wo - 1, (ix + pl) / stride);
@@ -461,11 +460,19 @@ __global__ __launch_bounds__(256) void weight_decay_kernel(const float* __restri
         if (threadIdx.x == 0) partial[(size_t)sgi * gridDim.x + blockIdx.x] = 0.5f * coef * ((red[0] + red[1]) + (red[2] + red[3]));
     }
 }
-__global__ __launch_bounds__(64) void weight_decay_finalize_kernel(const float* __restrict__ partial, int n, float* __restrict__ loss_out) {
+// (1024 threads: the ~7 000 block partials are seven loads per thread, not 110 dependent ones; lanes, then waves in order)
+__global__ __launch_bounds__(1024) void weight_decay_finalize_kernel(const float* __restrict__ partial, int n, float* __restrict__ loss_out) {
+    __shared__ double red[16];
     double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 64) s += (double)partial[i];
+    for (int i = threadIdx.x; i < n; i += 1024) s += (double)partial[i];
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (threadIdx.x == 0) *loss_out += (float)s;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = red[0];
+        for (int w = 1; w < 16; ++w) t += red[w];
+        *loss_out += (float)t;
+    }
 }
 
 // tf.train.AdamOptimizer step, the ApplyAdam kernel of TF 1.x op for op (one rounding per op, -ffp-contract=off):
@@ -605,7 +612,7 @@ int launch_bias_grad(const float* g, long M, int C, float* d_bias, float* partia
 
 int launch_max_pool_bwd(const unsigned char* argmax, const float* dy, float* dx, int N, int H, int W, int C, int Ho, int Wo,
                         int k, int stride, int pt, int pl, hipStream_t st) {
-    SN_REQUIRE(C % 4 == 0, "max_pool_bwd: C %% 4 != 0");
+    SN_REQUIRE(C % 4 == 0 && (long)N * H * W * (C / 4) < (1L << 32), "max_pool_bwd: C %% 4 != 0, or more than 2^32 channel quads");
     max_pool_bwd_kernel<<<cdiv((long)N * H * W * (C / 4), 256), 256, 0, st>>>(argmax, dy, dx, N, H, W, C, Ho, Wo, k, stride, pt, pl);
     SN_LAUNCH_CHECK("max_pool_bwd_kernel");
     return STABNET_OK;
@@ -649,7 +656,7 @@ int launch_weight_decay(const float* params, float* grads, const long* seg_off, 
                                                         loss_out != nullptr ? partial : nullptr);
     SN_LAUNCH_CHECK("weight_decay_kernel");
     if (loss_out != nullptr) {
-        weight_decay_finalize_kernel<<<1, 64, 0, st>>>(partial, 64 * nseg, loss_out);
+        weight_decay_finalize_kernel<<<1, 1024, 0, st>>>(partial, 64 * nseg, loss_out);
         SN_LAUNCH_CHECK("weight_decay_finalize_kernel");
     }
     return STABNET_OK;

@@ -286,6 +286,65 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict
         }
     }
 }
+// The same scatter for one channel with the accumulators of a 16 x 128 pixel tile (+ a 4 x 8 pixel halo) in LDS: a flow close to
+// the identity lands nearly every tap inside the window of its own tile, so the four 64-bit atomics of a pixel become LDS
+// atomics and each window element goes to memory ONCE (3 456 atomics per tile instead of 8 192, none of them contended: in the
+// direct form neighbouring pixels hit the same accumulators at the same time).  Taps outside the window go to memory directly:
+// any flow gives the same sums (integer adds), only the speed depends on it.
+constexpr int IB_TH = 16, IB_TW = 128, IB_HY = 4, IB_HX = 8, IB_WH = IB_TH + 2 * IB_HY, IB_WW = IB_TW + 2 * IB_HX;
+__global__ __launch_bounds__(256) void interp_bwd_tiled_kernel(const float* __restrict__ xs, const float* __restrict__ ys,
+                                                               const float* __restrict__ d_out, int H, int W,
+                                                               sn_u64* __restrict__ acc_fix) {
+    __shared__ sn_u64 win[IB_WH * IB_WW];
+    const int n = blockIdx.y;
+    const int tiles_x = (W + IB_TW - 1) / IB_TW;
+    const int ty0 = (int)(blockIdx.x / tiles_x) * IB_TH, tx0 = (int)(blockIdx.x % tiles_x) * IB_TW;
+    const int wy0 = ty0 - IB_HY, wx0 = tx0 - IB_HX;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    sn_u64* dimg = acc_fix + (size_t)n * H * W;
+    unsigned* poison = reinterpret_cast<unsigned*>(acc_fix + (size_t)gridDim.y * H * W);
+    for (int i = tid; i < IB_WH * IB_WW; i += 256) win[i] = 0ull;
+    __syncthreads();
+    auto add = [&](int y, int x, float v) {
+        const sn_u64 f = to_fix((double)v, poison);
+        const int ly = y - wy0, lx = x - wx0;
+        if ((unsigned)ly < (unsigned)IB_WH && (unsigned)lx < (unsigned)IB_WW) atomicAdd(&win[ly * IB_WW + lx], f);
+        else atomicAdd(&dimg[(size_t)y * W + x], f);
+    };
+    for (int r = wv; r < IB_TH; r += 4) {
+        const int y = ty0 + r;
+        if (y >= H) break;
+        const size_t rowoff = ((size_t)n * H + y) * W;
+#pragma unroll
+        for (int e = 0; e < IB_TW / 64; ++e) {
+            const int xx = tx0 + e * 64 + lane;
+            if (xx >= W) continue;
+            const float g = d_out[rowoff + xx];
+            if (g == 0.f) continue;                          // (NaN != 0: a NaN gradient goes on and poisons the sums)
+            const float xm = xs[rowoff + xx], ym = ys[rowoff + xx];
+            const float xp = (xm + 1.0f) * (float)W / 2.0f, yp = (ym + 1.0f) * (float)H / 2.0f;
+            int x0 = cvt_i32_x86_b(floorf(xp)), y0 = cvt_i32_x86_b(floorf(yp));
+            int x1 = x0 + 1, y1 = y0 + 1;
+            x0 = min(max(x0, 0), W - 1); x1 = min(max(x1, 0), W - 1);
+            y0 = min(max(y0, 0), H - 1); y1 = min(max(y1, 0), H - 1);
+            const float x0f = (float)x0, x1f = (float)x1, y0f = (float)y0, y1f = (float)y1;
+            const float wa = (x1f - xp) * (y1f - yp), wb = (x1f - xp) * (yp - y0f);
+            const float wc = (xp - x0f) * (y1f - yp), wd = (xp - x0f) * (yp - y0f);
+            add(y0, x0, wa * g);
+            add(y1, x0, wb * g);
+            add(y0, x1, wc * g);
+            add(y1, x1, wd * g);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < IB_WH * IB_WW; i += 256) {
+        const sn_u64 v = win[i];
+        if (v == 0ull) continue;
+        const int y = wy0 + i / IB_WW, x = wx0 + i % IB_WW;  // (only in-frame taps were ever added)
+        atomicAdd(&dimg[(size_t)y * W + x], v);
+    }
+}
+
 __global__ __launch_bounds__(256) void fix_to_float_kernel(const sn_u64* __restrict__ acc_fix, long n, float* __restrict__ out,
                                                            int accumulate) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -634,9 +693,15 @@ int stabnet_interp_bwd(const float* x, const float* y, const float* d_out, int N
         stabnet_set_error("interp_bwd: memset failed");
         return STABNET_ERR_LAUNCH;
     }
-    dim3 grid(cdiv((long)cdiv(W, 128) * H, 4), N, 1);
-    interp_bwd_kernel<<<grid, 256, 0, st>>>(x, y, d_out, H, W, C, static_cast<sn_u64*>(workspace));
-    SN_LAUNCH_CHECK("interp_bwd_kernel");
+    static const bool tiled = getenv("STABNET_INTERP_BWD_TILED") == nullptr || atoi(getenv("STABNET_INTERP_BWD_TILED")) != 0;   // debug switch
+    if (C == 1 && tiled) {
+        interp_bwd_tiled_kernel<<<dim3(cdiv(W, IB_TW) * cdiv(H, IB_TH), N), 256, 0, st>>>(x, y, d_out, H, W, static_cast<sn_u64*>(workspace));
+        SN_LAUNCH_CHECK("interp_bwd_tiled_kernel");
+    } else {
+        dim3 grid(cdiv((long)cdiv(W, 128) * H, 4), N, 1);
+        interp_bwd_kernel<<<grid, 256, 0, st>>>(x, y, d_out, H, W, C, static_cast<sn_u64*>(workspace));
+        SN_LAUNCH_CHECK("interp_bwd_kernel");
+    }
     fix_to_float_kernel<<<cdiv(total, 256), 256, 0, st>>>(static_cast<const sn_u64*>(workspace), total, d_im, accumulate);
     SN_LAUNCH_CHECK("fix_to_float_kernel");
     return STABNET_OK;

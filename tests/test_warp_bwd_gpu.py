@@ -55,14 +55,20 @@ def test_transformer_and_mesh_losses_backward(cuda, N, H, W, C, std):
     assert lv[3] == pytest.approx(float(T.get_consistency_loss(pts2, ocfg)), rel=1e-4)
 
 
-def test_interp_backward(cuda):
+# (near-identity flow, one tile) / several 16 x 128 tiles with halo traffic between them / a flow that sends every tap far from its
+# tile (the kernel's direct-to-memory path) / two channels (the untiled kernel)
+@pytest.mark.parametrize("N,H,W,C,flow", [(2, 45, 77, 1, 0.05), (2, 70, 300, 1, 0.05), (1, 70, 300, 1, None), (1, 33, 130, 2, 0.05)])
+def test_interp_backward(cuda, N, H, W, C, flow):
     from stabnet_amd import train_ops
-    N, H, W, C = 2, 45, 77, 1
     rng = np.random.default_rng(4)
     im = rng.standard_normal((N, H, W, C)).astype(np.float32)
     gx, gy = np.meshgrid(np.linspace(-1, 1, W), np.linspace(-1, 1, H))
-    x = (gx[None] + rng.normal(0, 0.05, (N, H, W))).astype(np.float32)
-    y = (gy[None] + rng.normal(0, 0.05, (N, H, W))).astype(np.float32)
+    if flow is None:
+        x = rng.uniform(-1.2, 1.2, (N, H, W)).astype(np.float32)
+        y = rng.uniform(-1.2, 1.2, (N, H, W)).astype(np.float32)
+    else:
+        x = (gx[None] + rng.normal(0, flow, (N, H, W))).astype(np.float32)
+        y = (gy[None] + rng.normal(0, flow, (N, H, W))).astype(np.float32)
     g = rng.standard_normal((N, H, W, C)).astype(np.float32)
     imt = T.t(im, requires_grad=True)
     corners = O._interpolate(im, x.reshape(-1), y.reshape(-1))[1]
