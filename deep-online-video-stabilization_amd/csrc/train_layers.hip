@@ -94,6 +94,8 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const ColGroups G, long
 // combine through LDS (deterministic).  Returns the two sums in lane 0 of each channel.  These kernels are latency bound (a
 // handful of blocks, each lane a serial chain of L2-latency loads): 16 channels x 64 lanes per 1024-thread block keeps the
 // chain at chunks / 64 iterations (was 64 channels x 16 lanes: 9.9 us for two towers' 512 chunks, now a third of that).
+// Measured and not kept (rocprofv3, 6.3-6.7 us per launch as it stands): eight chunk loads issued together (12-13 us: 120
+// VGPRs at 1024 threads), the final 63-term sum by lane 0 only instead of by every thread (7.1-7.2 us).
 constexpr int FIN_LANES = 64, FIN_CH = 16;
 __device__ __forceinline__ void combine_partials(const float* __restrict__ partial, int chunks, int C, int c, int lane,
                                                  double& s0, double& s1) {
