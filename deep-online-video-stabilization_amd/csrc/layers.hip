@@ -192,7 +192,20 @@ __global__ __launch_bounds__(256) void fc_lds_kernel(const float* __restrict__ x
         }
     };
     load_row(wv, n, 0);
-    for (int i = tid * 4; i < M * K; i += 256 * 4) *reinterpret_cast<float4*>(xs + i) = *reinterpret_cast<const float4*>(x + i);
+    // (eight loads in flight per thread: one at a time the 32 trips of this staging loop were 32 L2 round trips, most of the kernel)
+    for (int i0 = tid * 4; i0 < M * K; i0 += 256 * 4 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + j * 1024;
+            v[j] = (i < M * K) ? *reinterpret_cast<const float4*>(x + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + j * 1024;
+            if (i < M * K) *reinterpret_cast<float4*>(xs + i) = v[j];
+        }
+    }
     __syncthreads();
     for (; n < Nout; n += waves) {
         float acc[16];

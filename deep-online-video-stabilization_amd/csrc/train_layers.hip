@@ -314,13 +314,22 @@ __global__ __launch_bounds__(256) void fc_bwd_w_kernel(const float* __restrict__
     const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float bacc = 0.f;
-    for (int m = 0; m < M; ++m) {
-        float d = dy[(size_t)m * Nout + n];
-        if (relu && !(y[(size_t)m * Nout + n] > 0.f)) d = 0.f;
-        bacc += d;
-        if (k < K) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * K + k);
-            acc.x += d * xv.x; acc.y += d * xv.y; acc.z += d * xv.z; acc.w += d * xv.w;
+    const bool k_ok = k < K;
+    for (int m0 = 0; m0 < M; m0 += 8) {                    // eight rows' loads in flight, added in row order
+        float4 xv[8];
+        float d[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = min(m0 + j, M - 1);
+            xv[j] = k_ok ? *reinterpret_cast<const float4*>(x + (size_t)m * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            d[j] = dy[(size_t)m * Nout + n];
+            if (relu && !(y[(size_t)m * Nout + n] > 0.f)) d[j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (m0 + j >= M) break;
+            bacc += d[j];
+            acc.x += d[j] * xv[j].x; acc.y += d[j] * xv[j].y; acc.z += d[j] * xv[j].z; acc.w += d[j] * xv[j].w;
         }
     }
     if (k < K) {
