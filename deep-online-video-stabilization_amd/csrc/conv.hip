@@ -267,12 +267,24 @@ static int launch_ring(const ConvArgs& a, hipStream_t st) {
 // per CU; the slices must be equal (steps % 3 == 0).  Measured at 720p (rocprofv3 inside the graph replay, block-3 conv2, M = 3600,
 // N = 256, K = 2304): 45.3 us against 45.8 us + a 4.9 us reduce launch.  The register-staged kernel's two-group form lost
 // (30.8 vs 24.3 + 4.9 us) and was removed.
-static int conv_kgroups(const ConvArgs& a, bool ring) {
+// Two groups with the fragment prologue (conv_ring_f32_kernel<0, 0, 2, 1>): the 1x1 layers that carry a BN + ReLU prologue AND
+// split K in two (the block-3 conv1 layers of a 720p frame, K = 1024: register-staged kernel x 2 slices + slabs + a reduce launch
+// before) as one 8-wave workgroup per tile.
+static bool ring_pro_geometry(const ConvArgs& a, bool has_prologue) {
+    static const int on = env_int("STABNET_CONV_RING_PRO", 1);
+    if (g_ring < 0) g_ring = env_int("STABNET_CONV_RING", 1);
+    return on && g_ring && !g_bf16_operands && !g_force_bk16 && has_prologue && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 &&
+           a.up == 1 && a.Cin % 32 == 0 && !a.rowrun && a.x_ld == a.Cin;
+}
+static int conv_kgroups(const ConvArgs& a, bool ring, bool has_prologue) {
     static const int on = env_int("STABNET_CONV_KGROUPS", 1);
+    static const int on2 = env_int("STABNET_CONV_KGROUPS_PRO", 1);
     if (!on || a.splitk < 2 || g_bf16_operands) return 1;
     const int steps = conv_total_steps(a);
     if (a.steps_per_split * a.splitk != steps) return 1;
-    return (ring && a.splitk == 3 && !a.rowrun) ? 3 : 1;
+    if (ring && a.splitk == 3 && !a.rowrun) return 3;
+    if (on2 && !ring && a.splitk == 2 && ring_pro_geometry(a, has_prologue)) return 2;
+    return 1;
 }
 
 static int g_cus = 0;
@@ -286,17 +298,18 @@ static int device_cus() {
     return g_cus;
 }
 
-static int launch_ring_kg3(const ConvArgs& a, hipStream_t st) {
+static int launch_ring_kg(const ConvArgs& a, int kg, hipStream_t st) {
     const int cus = device_cus();
     if (cus <= 0) {
         stabnet_set_error("conv: cannot read the CU count");
         return STABNET_ERR_LAUNCH;
     }
     const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64);
-    const int grid = (int)std::min<long>(ntiles, cus);                 // 144 KiB of LDS: one workgroup per CU
-    if (a.pad == 0) conv_ring_f32_kernel<0, 0, 3><<<grid, 768, 0, st>>>(a);
+    const int grid = (int)std::min<long>(ntiles, cus);                 // 144 (102) KiB of LDS: one workgroup per CU
+    if (kg == 2) conv_ring_f32_kernel<0, 0, 2, 1><<<grid, 512, 0, st>>>(a);
+    else if (a.pad == 0) conv_ring_f32_kernel<0, 0, 3><<<grid, 768, 0, st>>>(a);
     else conv_ring_f32_kernel<1, 0, 3><<<grid, 768, 0, st>>>(a);
-    SN_LAUNCH_CHECK("conv_ring_f32_kernel<KG=3>");
+    SN_LAUNCH_CHECK("conv_ring_f32_kernel<KG>");
     return STABNET_OK;
 }
 
@@ -335,7 +348,7 @@ int conv_reduce_launches(const ConvArgs& a) {
     int splitk_unused = 1;
     const int t = pick_tile(a, splitk_unused);
     const bool ring = ring_eligible(a, t, a.in_scale_expected != 0);
-    return (t == T64x64 && conv_kgroups(a, ring) > 1) ? 0 : 1;
+    return (t == T64x64 && conv_kgroups(a, ring, a.in_scale_expected != 0) > 1) ? 0 : 1;
 }
 
 int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands) {
@@ -353,12 +366,12 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands
     const bool rec = prof != nullptr && prof->begin(st);
     const bool ring = ring_eligible(a, t);
     SN_REQUIRE(ring || a.x_ld == a.Cin, "conv: a strided input (x_ld %d != Cin %d) needs the ring kernel", a.x_ld, a.Cin);
-    const int kg = (t == T64x64) ? conv_kgroups(a, ring) : 1;
-    const bool pro = !ring && t == T64x64 && bk32 && ring_pro_eligible(a);
+    const int kg = (t == T64x64) ? conv_kgroups(a, ring, a.in_scale != nullptr) : 1;
+    const bool pro = kg == 1 && !ring && t == T64x64 && bk32 && ring_pro_eligible(a);
     if (pro) {
         rc = launch_ring_pro(a, 0, st);
     } else if (kg > 1) {
-        rc = launch_ring_kg3(a, st);
+        rc = launch_ring_kg(a, kg, st);
     } else if (ring) {
         rc = launch_ring(a, st);
     } else if (bk32) {
@@ -375,7 +388,7 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands
     if (pro) {
         kind = PK_KERNEL_CONV_KG + 2;
     } else if (kg > 1) {
-        kind = PK_KERNEL_CONV_KG + mode;
+        kind = kg == 2 ? PK_KERNEL_CONV_KG + 3 : PK_KERNEL_CONV_KG + mode;
     } else if (!ring) {                                                  // + 18 for the one-stage (NBUF = 1), + 36 for the bf16-operand instantiation
         int bm, bn, nbuf, bf16;
         tile_dims(t, bm, bn);

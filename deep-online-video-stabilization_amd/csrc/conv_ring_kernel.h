@@ -65,13 +65,13 @@ typedef __bf16 sn_bf16x8 __attribute__((ext_vector_type(8)));
 template <int MODE /* 0: no padding, 1: zero padding, 2: row-run A operand on a zero-BORDERED image (ConvArgs::rowrun) */,
           int BF16 = 0 /* 1: fragments rounded to bf16 at read time, v_mfma_f32_32x32x16_bf16 (conv_launch's bf16_operands) */,
           int KG = 1 /* K groups of 4 waves: split-K inside the workgroup (p.splitk == KG), see the header comment */,
-          int PRO = 0 /* 1: BN + ReLU prologue on the A fragments (MODE 0, KG 1 only), pair of towers as one launch */>
+          int PRO = 0 /* 1: BN + ReLU prologue on the A fragments (MODE 0 only); KG = 1: the pair of towers as one launch */>
 __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs p) {
     constexpr int BM = 64, BN = 64, BK = 32;
     constexpr int STAGE = (BM + BN) * BK;                  // floats
-    static_assert(!PRO || (MODE == 0 && KG == 1 && BF16 == 0), "the fragment prologue exists for the plain 1x1 fp32 kernel");
-    constexpr int SC_FLOATS = PRO ? 3 * 4 * 64 : 0;        // per stage and wave: 32 scales + 32 shifts, behind the ring
-    __shared__ __attribute__((aligned(16))) float ring[KG * 3 * STAGE + SC_FLOATS];
+    static_assert(!PRO || (MODE == 0 && BF16 == 0), "the fragment prologue exists for the 1x1 fp32 kernel");
+    constexpr int SC_FLOATS = PRO ? 3 * 4 * 64 : 0;        // per group, stage and wave: 32 scales + 32 shifts, behind the rings
+    __shared__ __attribute__((aligned(16))) float ring[KG * 3 * STAGE + KG * SC_FLOATS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (KG > 1) ? ((tid >> 6) & 3) : (tid >> 6);
     const int grp = (KG > 1) ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;      // K group = K slice of this wave
@@ -100,9 +100,11 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     const unsigned lds_base = (unsigned)(size_t)(sn_lds_ptr_t)ring + (KG > 1 ? (unsigned)grp * (3u * STAGE * 4u) : 0u);   // this group's ring
 
     // PRO: the pair of towers (see the header comment)
-    const long pair_delta = PRO ? (long)(size_t)p.out_floor : 0L;
-    const int m_tower = (PRO && pair_delta != 0) ? (p.M >> 1) : 0x7fffffff;
-    const unsigned sc_base = lds_base + 3u * STAGE * 4u;   // [slot][wave][scale 32 | shift 32]
+    // (KG > 1 with PRO -- the inference conv1 layers that split K -- is one tower and out_floor is an ordinary floor vector)
+    const long pair_delta = (PRO && KG == 1) ? (long)(size_t)p.out_floor : 0L;
+    const int m_tower = (PRO && KG == 1 && pair_delta != 0) ? (p.M >> 1) : 0x7fffffff;
+    const unsigned sc_base = (KG > 1) ? (unsigned)(size_t)(sn_lds_ptr_t)ring + (unsigned)(KG * 3 * STAGE * 4) + (unsigned)grp * (unsigned)(SC_FLOATS * 4)
+                                      : lds_base + 3u * STAGE * 4u;   // [slot][wave][scale 32 | shift 32]
     // consumer steps of this workgroup (every slice has steps_per_split steps except the last one)
     int remaining = 0;
     for (int t = t_first; t < t_end; t += t_stride) remaining += (t / tiles_mn == p.splitk - 1) ? last_slice_steps : p.steps_per_split;

@@ -640,6 +640,7 @@ const char* stabnet_prof_kind_name(int kind) {
     if (kind == PK_KERNEL_CONV_KG) return "conv_ring_f32_kernel<0, 0, 3, 0>";
     if (kind == PK_KERNEL_CONV_KG + 1) return "conv_ring_f32_kernel<1, 0, 3, 0>";
     if (kind == PK_KERNEL_CONV_KG + 2) return "conv_ring_f32_kernel<0, 0, 1, 1>";
+    if (kind == PK_KERNEL_CONV_KG + 3) return "conv_ring_f32_kernel<0, 0, 2, 1>";
     // names as rocprofv3 prints the template instantiation <MODE, BF16>
     if (kind == PK_KERNEL_CONV_RING) return "conv_ring_f32_kernel<0, 0, 1, 0>";
     if (kind == PK_KERNEL_CONV_RING + 1) return "conv_ring_f32_kernel<1, 0, 1, 0>";

@@ -124,3 +124,56 @@ def test_split_k_inside_the_workgroup(cuda, N, H, W, Cin, Cout, k, stride, pad, 
         assert np.abs(got - want).max() <= (4e-5 if out_bn else 2e-5) * scale
     assert np.array_equal(got3, got3b)                   # groups are added in group order: the same bits every time
     assert np.abs(got3 - got1).max() <= 1e-5 * scale     # three slices vs one: float32 summation order only
+
+
+# two K slices inside the workgroup WITH the fragment prologue (conv_ring_f32_kernel<0, 0, 2, 1>): the 1x1 layers that carry a
+# BN + ReLU prologue and split K in two -- block-3 conv1 of a 720p frame (M = 3600, N = 256, K = 1024) and smaller relatives
+KG2_CASES = [
+    (1, 9, 16, 64, 64, False, 0, False),          # 2 K-steps: one per group, a single ragged tile
+    (1, 17, 23, 192, 96, True, 1, True),          # 6 steps, ragged M and Cout tiles, bias + residual + ReLU
+    (1, 45, 80, 1024, 256, False, 0, False),      # the 720p block-3 conv1 shape: 57 x 4 tiles, 16 steps per group
+    (1, 150, 160, 128, 64, True, 0, True),        # 375 tiles > 256 CUs: the rings run across tile boundaries
+    (2, 20, 24, 160, 64, False, 0, False),        # 5 steps: the slices are unequal -> stays on the slab path (still correct)
+]
+
+
+@pytest.mark.parametrize("out_bn", [False, True])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,bias,res,relu", KG2_CASES)
+def test_two_k_groups_with_prologue(cuda, N, H, W, Cin, Cout, bias, res, relu, out_bn):
+    from stabnet_amd import _lib, ops
+    rng = np.random.default_rng(Cin * 3 + Cout + H)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((1, 1, Cin, Cout)) * np.sqrt(2.0 / Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32) if bias else None
+    sc = rng.uniform(0.5, 1.5, Cin).astype(np.float32)
+    sh = (rng.standard_normal(Cin) * 0.3).astype(np.float32)
+    a = np.maximum(x * sc + sh, 0).astype(np.float32)
+    want = O.conv2d(a, w, 1, ((0, 0), (0, 0)), b)
+    r = None
+    if res:
+        r = rng.standard_normal(want.shape).astype(np.float32)
+        want = want + r
+    osc = osh = None
+    if out_bn:
+        osc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+        osh = (rng.standard_normal(Cout) * 0.3).astype(np.float32)
+        want = (want * osc + osh).astype(np.float32)
+    if relu:
+        want = np.maximum(want, 0)
+    t = lambda v: None if v is None else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(cuda)
+    args = (t(x), t(ops.pack_conv_weight(w)), t(b), t(sc), t(sh), t(r), 1, 1, 0, relu)
+    L = _lib.lib()
+    try:
+        L.stabnet_conv_tuning_override(2, 2)             # the 64 x 64 tile, two K slices
+        got2 = ops.conv2d(*args, out_scale=t(osc), out_shift=t(osh)).cpu().numpy()
+        got2b = ops.conv2d(*args, out_scale=t(osc), out_shift=t(osh)).cpu().numpy()
+        L.stabnet_conv_tuning_override(2, 1)
+        got1 = ops.conv2d(*args, out_scale=t(osc), out_shift=t(osh)).cpu().numpy()
+    finally:
+        L.stabnet_conv_tuning_override(-1, -1)
+    scale = np.abs(want).max()
+    for got in (got2, got1):
+        assert got.shape == want.shape and np.isfinite(got).all()
+        assert np.abs(got - want).max() <= (4e-5 if out_bn else 2e-5) * scale
+    assert np.array_equal(got2, got2b)
+    assert np.abs(got2 - got1).max() <= 1e-5 * scale

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of two builds of the library under rocprofv3 (kernel durations inside the hipGraph replay):
 #   gpurun -- 'bash tools/ab_rocprof_lib.sh <other libstabnet_hip.so> <tag> [kernel name substring]'
-OTHER=$1; TAG=$2; PAT=${3:-warp_sample}
+OTHER=$(realpath $1); TAG=$2; PAT=${3:-warp_sample}
 R=$PWD; export TMPDIR=/tmp; O=$R/gpurun_out
 cd /tmp
 for name in new old; do
