@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ g
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     slab_sum(e.slab[0] + i, e.splits, e.elems, acc);
     if (e.slab[1] != nullptr) slab_sum(e.slab[1] + i, e.splits, e.elems, acc);
-    float4* d = reinterpret_cast<float4*>(grads + e.dw_off + i);
+    float4* d = reinterpret_cast<float4*>(sn_float_at(grads, e.dw_off + i));
     float4 o = *d;
     o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
     *d = o;
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(float* __restrict__ 
     if (grp == 0) {
         float4 s = sh[0][col];
         for (int g = 1; g < 4; ++g) { const float4 u = sh[g][col]; s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w; }
-        float4* d = reinterpret_cast<float4*>(grads + e.dw_off + i);
+        float4* d = reinterpret_cast<float4*>(sn_float_at(grads, e.dw_off + i));
         float4 o = *d;
         o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
         *d = o;
@@ -489,7 +489,7 @@ int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* 
                    float* slab_base, size_t* slab_cursor, size_t slab_capacity, WgradReduceTable* table, hipStream_t st, Prof* prof,
                    int rowrun, long bias_off, long bias_off2) {
     WgradArgs a{};
-    a.x = x[0]; a.dy = dy[0]; a.dw = dw_base + dw_off; a.in_scale = in_scale ? in_scale[0] : nullptr; a.in_shift = in_shift ? in_shift[0] : nullptr;
+    a.x = x[0]; a.dy = dy[0]; a.dw = sn_float_at(dw_base, dw_off); a.in_scale = in_scale ? in_scale[0] : nullptr; a.in_shift = in_shift ? in_shift[0] : nullptr;
     if (T == 2) { a.x2 = x[1]; a.dy2 = dy[1]; a.in_scale2 = in_scale ? in_scale[1] : nullptr; a.in_shift2 = in_shift ? in_shift[1] : nullptr; }
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.Ho = (H + 2 * pad - KH) / stride + 1;
@@ -508,8 +508,8 @@ int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* 
     const bool bias = bias_off >= 0;
     SN_REQUIRE(!bias || (!rowrun && wgrad_bias_fusable(N, H, W, Cin, Cout, KH, KW, stride, pad)), "wgrad: this layer cannot carry its bias gradient");
     SN_REQUIRE(bias || bias_off2 < 0, "wgrad: second bias without a first");
-    a.dbias = bias ? dw_base + bias_off : nullptr;
-    a.dbias2 = bias_off2 >= 0 ? dw_base + bias_off2 : nullptr;
+    a.dbias = bias ? sn_float_at(dw_base, bias_off) : nullptr;
+    a.dbias2 = bias_off2 >= 0 ? sn_float_at(dw_base, bias_off2) : nullptr;
     WgradReduceTable local{};
     if (total > 1) {
         SN_REQUIRE(slab_base != nullptr && slab_cursor != nullptr, "wgrad: %d splits need a slab workspace", total);
@@ -557,7 +557,7 @@ int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* 
     } else {
         conv_wgrad_f32_kernel<<<grid, 256, 0, st>>>(a);
     }
-    if (rec) prof->end(st, same ? PK_KERNEL_WGRAD_SAME + 2 * (KH == 3 ? 1 : 0) + (pro ? 1 : 0) : PK_KERNEL_WGRAD, 2.0 * T * a.M * (double)a.K * Cout,
+    if (rec) prof->end(st, same ? PK_KERNEL_WGRAD_SAME + 2 * (KH == 3 ? 1 : 0) + (pro ? 1 : 0) + ((KH == 1 && bias) ? 4 : 0) : PK_KERNEL_WGRAD, 2.0 * T * a.M * (double)a.K * Cout,
                        4.0 * T * ((double)a.M * Cout + (double)N * H * W * Cin + (double)a.K * Cout * splits), Cout, a.K, T * a.M, total);
     SN_LAUNCH_CHECK("conv_wgrad_f32_kernel");
     if (total > 1 && table == nullptr) return wgrad_reduce_flush(dw_base, local, st);
@@ -726,7 +726,7 @@ int stabnet_conv2d_wgrad_bias(const float* x, const float* dy, float* dw, float*
     // (one base for both gradients: the bias is addressed relative to dw, as the training step addresses its flat gradient buffer)
     return wgrad_launch_g(1, xs, dys, dw, 0, in_scale ? sc : nullptr, in_scale ? sh : nullptr, N, H, W, Cin, Cout, 1, 1, 1, 0,
                           static_cast<float*>(workspace), &cursor, workspace_bytes / sizeof(float), nullptr, (hipStream_t)stream, nullptr,
-                          0, (long)(d_bias - dw), -1);
+                          0, sn_float_distance(dw, d_bias), -1);
 }
 
 /* The same gradient for a layer whose channel count is NOT a multiple of 4 (the 13-channel stem, train_bundle_nobm.py's

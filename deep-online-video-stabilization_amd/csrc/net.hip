@@ -627,9 +627,10 @@ const char* stabnet_prof_kind_name(int kind) {
         case PK_KERNEL_WGRAD: return "conv_wgrad_f32_kernel";
         default: break;
     }
-    if (kind >= PK_KERNEL_WGRAD_SAME && kind < PK_KERNEL_WGRAD_SAME + 4) {
-        static const char* const names[4] = {"conv_wgrad_same_f32_kernel<0, 0>", "conv_wgrad_same_f32_kernel<0, 1>",
-                                             "conv_wgrad_same_f32_kernel<1, 0>", "conv_wgrad_same_f32_kernel<1, 1>"};
+    if (kind >= PK_KERNEL_WGRAD_SAME && kind < PK_KERNEL_WGRAD_SAME + 6) {      // names as rocprofv3 prints them: <K3, PRO, BIAS>
+        static const char* const names[6] = {"conv_wgrad_same_f32_kernel<0, 0, 0>", "conv_wgrad_same_f32_kernel<0, 1, 0>",
+                                             "conv_wgrad_same_f32_kernel<1, 0, 0>", "conv_wgrad_same_f32_kernel<1, 1, 0>",
+                                             "conv_wgrad_same_f32_kernel<0, 0, 1>", "conv_wgrad_same_f32_kernel<0, 1, 1>"};
         return names[kind - PK_KERNEL_WGRAD_SAME];
     }
     if (kind >= PK_KERNEL_CONV_PAIR && kind < PK_KERNEL_CONV_PAIR + 4) {
@@ -1223,7 +1224,7 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
             // reduction accumulates into: addressed relative to `grads`, as every entry of the table is), then moves to OHWI
             float* dw_rr = ws[0] + L.stem_dw;
             if (hipMemsetAsync(dw_rr, 0, net->stem_w_floats * sizeof(float), st) != hipSuccess) return STABNET_ERR_LAUNCH;
-            if ((rc = wgrad(Xin, CV(bGB, c1.size), (long)(dw_rr - grads), -1, net->H, net->W, net->in_ch, 64, 7, 2, 3, 1)) != 0) return rc;
+            if ((rc = wgrad(Xin, CV(bGB, c1.size), sn_float_distance(grads, dw_rr), -1, net->H, net->W, net->in_ch, 64, 7, 2, 3, 1)) != 0) return rc;
             if ((rc = wgrad_reduce_flush(grads, table, st)) != 0) return rc;
             return launch_wgrad_rowrun_scatter(dw_rr, grads + net->w_stem, 64, 7, 7, net->in_ch, net->in_ch_pad, st);
         }

@@ -45,6 +45,18 @@ int launch_adam(float* w, const float* g, const float* g2, float* m, float* v, l
 struct WgradReduceEntry { long dw_off, elems; const float* slab[2]; int splits; };   // slab[t]: tower t's [splits][elems] partials (or null)
 struct WgradReduceTable { WgradReduceEntry e[WGRAD_TABLE_MAX]; long prefix[WGRAD_TABLE_MAX + 1]; int n; };
 int wgrad_splits(int Cout, int K, int M, int* rows_per_split);
+// A reduce-table destination is `dw_off` floats from the table's base address.  Most lie inside the caller's gradient buffer; the
+// row-run stem's scratch gradient and a stand-alone bias (stabnet_conv2d_wgrad_bias) are other allocations, so the distance is
+// taken between ADDRESSES and applied to the address, never as pointer arithmetic across objects.
+inline long sn_float_distance(const float* base, const float* p) {
+    return (long)(((intptr_t)reinterpret_cast<uintptr_t>(p) - (intptr_t)reinterpret_cast<uintptr_t>(base)) / (intptr_t)sizeof(float));
+}
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline float* sn_float_at(float* base, long floats) {
+    return reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(base) + (uintptr_t)(floats * (long)sizeof(float)));
+}
 size_t wgrad_slab_floats(int Cout, int K, int M, int T, int with_bias = 0);
 int wgrad_reduce_flush(float* grads, WgradReduceTable& t, hipStream_t st);
 // T towers (1 or 2) in ONE launch: grid.z = T * splits, slabs [tower][split]; the reduce adds them in that order into dw
