@@ -68,7 +68,13 @@ def test_rowrun_stem_training_step_equals_the_padded_stem(cuda, tmp_path):
         if name in ("resnet_v2_50/conv1/weights", "resnet_v2_50/conv1/biases"):
             n = int(np.prod([d for d in dims if d > 0]))
             sa, sb = ga[off:off + n], gb[off:off + n]
-            assert np.abs(sb).max() > 0
-            assert np.linalg.norm(sa - sb) <= 5e-3 * np.linalg.norm(sb), name
-            if name.endswith("weights"):                                     # pad channels 13..15 of OHWI [64][7][7][16] get nothing
+            if name.endswith("weights"):
+                w_scale = np.abs(sb).max()
+                assert w_scale > 0
+                assert np.linalg.norm(sa - sb) <= 5e-3 * np.linalg.norm(sb), name
+                # pad channels 13..15 of OHWI [64][7][7][16] get nothing
                 assert not sa.reshape(dims)[..., aux:].any() and not sb.reshape(dims)[..., aux:].any()
+            else:
+                # a bias in front of max-pool + batch norm has a gradient of exactly zero in exact arithmetic (BN removes the
+                # shift): both forms leave float32 cancellation noise, far below the weights' gradient
+                assert max(np.abs(sa).max(), np.abs(sb).max()) <= 1e-3 * w_scale, name
