@@ -524,11 +524,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Row chunks of a column reduction over [M][C]: about 512 blocks in all ((C/64) x chunks, two per CU; measured 2048 / 1024 /
-// 768 / 512 / 384 / 256 -> 389.6 / 394.7 / 398.0 / 400.0 / 399.5 / 395.4 pairs/s: more chunks speed the reduction up but
-// slow the single-block-per-64-channels finalize down), at least 64 rows per chunk.
+// Row chunks of a column reduction over [M][C]: about 256 blocks PER TOWER ((C/64) x chunks; both towers are one launch, so
+// 512 blocks = two per CU in all.  Measured per tower, one tower per launch, round 1: 2048 / 1024 / 768 / 512 / 384 / 256 ->
+// 389.6 / 394.7 / 398.0 / 400.0 / 399.5 / 395.4 pairs/s; with the towers paired, round 3: 2048 / 1024 / 512 / 384 / 256 / 192 /
+// 128 -> 521.4 / 523.1 / 523.6 / 524.4 / 526.3 / 525.4 / 525.6: more chunks speed the reduction up but slow the
+// single-block-per-16-channels finalize down), at least 64 rows per chunk.
 static int reduce_chunks(long M, int C, long& rows_per_chunk) {
-    static const int target = []() { const char* v = getenv("STABNET_REDUCE_BLOCKS"); return v ? atoi(v) : 512; }();
+    static const int target = []() { const char* v = getenv("STABNET_REDUCE_BLOCKS"); return v ? atoi(v) : 256; }();
     const long want = std::max<long>(target / cdiv(C, 64), 16);
     int chunks = (int)std::min<long>(std::max<long>(M / 64, 1), want);
     rows_per_chunk = (M + chunks - 1) / chunks;
