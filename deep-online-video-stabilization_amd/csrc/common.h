@@ -34,3 +34,15 @@ void stabnet_set_error(const char* fmt, ...);
 int sn_check_device(const void* p, const char* what, hipStream_t st = nullptr);   // (skipped while `st` is being captured)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+#ifdef __HIPCC__
+// Workgroup ids are dealt round-robin over the 8 XCDs, each with its own L2.  A kernel whose neighbouring workgroups re-read each
+// other's input (pool windows, sampler taps) works as id sn_xcd_band(blockIdx.x, gridDim.x) instead: the ids of one XCD then
+// cover ONE contiguous eighth of the range (balanced when the count is not a multiple of 8), and the shared input is fetched
+// into one L2 instead of several.  A bijection on [0, nb).
+__device__ __forceinline__ unsigned sn_xcd_band(unsigned b, unsigned nb) {
+    if (nb < 8u) return b;
+    const unsigned xcd = b & 7u, per = nb >> 3, rem = nb & 7u;
+    return xcd * per + (xcd < rem ? xcd : rem) + (b >> 3);
+}
+#endif

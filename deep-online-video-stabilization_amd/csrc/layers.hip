@@ -29,15 +29,15 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restri
 __global__ __launch_bounds__(256) void max_pool_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H,
                                                        int W, int C, int Ho, int Wo, int k, int stride, int pt, int pl,
                                                        const float* __restrict__ scale, const float* __restrict__ shift) {
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    const int c4n = C / 4;
-    const long total = (long)N * Ho * Wo * c4n;
-    if (q >= total) return;
+    // (XCD-banded ids: the windows of neighbouring output rows share an input row; 32-bit index math, host-checked)
+    const unsigned q = sn_xcd_band(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+    const unsigned c4n = (unsigned)C / 4u;
+    if (q >= (unsigned)N * Ho * Wo * c4n) return;
     const int c = (int)(q % c4n) * 4;
-    long r = q / c4n;
-    const int ox = (int)(r % Wo); r /= Wo;
-    const int oy = (int)(r % Ho);
-    const int n = (int)(r / Ho);
+    unsigned r = q / c4n;
+    const int ox = (int)(r % (unsigned)Wo); r /= (unsigned)Wo;
+    const int oy = (int)(r % (unsigned)Ho);
+    const int n = (int)(r / (unsigned)Ho);
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     for (int dy = 0; dy < k; ++dy) {
         const int iy = oy * stride - pt + dy;
@@ -295,7 +295,7 @@ int launch_pad_channels(const float* x, float* y, long npix, int C, int Cp, hipS
 
 int launch_max_pool(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, int k, int stride, int pt,
                     int pl, const float* scale, const float* shift, hipStream_t st) {
-    SN_REQUIRE(C % 4 == 0, "max_pool: C %% 4 != 0");
+    SN_REQUIRE(C % 4 == 0 && (long)N * Ho * Wo * (C / 4) < (1L << 32), "max_pool: C %% 4 != 0, or more than 2^32 channel quads");
     max_pool_kernel<<<cdiv((long)N * Ho * Wo * (C / 4), 256), 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, k, stride, pt, pl, scale, shift);
     SN_LAUNCH_CHECK("max_pool_kernel");
     return STABNET_OK;

@@ -265,15 +265,16 @@ __global__ __launch_bounds__(256) void max_pool_bwd_kernel(const unsigned char* 
 __global__ __launch_bounds__(256) void max_pool_argmax_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               unsigned char* __restrict__ argmax, int N, int H, int W, int C,
                                                               int Ho, int Wo, int k, int stride, int pt, int pl) {
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    const int c4n = C / 4;
-    const long total = (long)N * Ho * Wo * c4n;
-    if (q >= total) return;
+    // (32-bit index math, host-checked.  XCD-banded ids -- sn_xcd_band, as the inference pool uses -- were measured on both
+    //  training pool kernels at 8 x 144 x 256 x 64 per tower and lost: 22.9 -> 23.9 us here, 33.7 -> 37.3 us in the backward)
+    const unsigned q = blockIdx.x * 256u + threadIdx.x;
+    const unsigned c4n = (unsigned)C / 4u;
+    if (q >= (unsigned)N * Ho * Wo * c4n) return;
     const int c = (int)(q % c4n) * 4;
-    long r = q / c4n;
-    const int ox = (int)(r % Wo); r /= Wo;
-    const int oy = (int)(r % Ho);
-    const int n = (int)(r / Ho);
+    unsigned r = q / c4n;
+    const int ox = (int)(r % (unsigned)Wo); r /= (unsigned)Wo;
+    const int oy = (int)(r % (unsigned)Ho);
+    const int n = (int)(r / (unsigned)Ho);
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     for (int dyy = 0; dyy < k; ++dyy) {
@@ -633,7 +634,7 @@ int launch_max_pool_bwd(const unsigned char* argmax, const float* dy, float* dx,
 
 int launch_max_pool_argmax(const float* x, float* y, unsigned char* argmax, int N, int H, int W, int C, int Ho, int Wo, int k,
                            int stride, int pt, int pl, hipStream_t st) {
-    SN_REQUIRE(k * k <= 255 && C % 4 == 0, "max_pool: window too large for the argmax byte, or C %% 4 != 0");
+    SN_REQUIRE(k * k <= 255 && C % 4 == 0 && (long)N * Ho * Wo * (C / 4) < (1L << 32), "max_pool: window too large for the argmax byte, C %% 4 != 0, or more than 2^32 channel quads");
     max_pool_argmax_kernel<<<cdiv((long)N * Ho * Wo * (C / 4), 256), 256, 0, st>>>(x, y, argmax, N, H, W, C, Ho, Wo, k, stride, pt, pl);
     SN_LAUNCH_CHECK("max_pool_argmax_kernel");
     return STABNET_OK;

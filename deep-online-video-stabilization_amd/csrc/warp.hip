@@ -106,9 +106,7 @@ __global__ __launch_bounds__(256) void warp_sample_kernel(const float* __restric
     const int segs = (W + 64 * PX - 1) / (64 * PX);           // wave segments per row
     // workgroup ids are dealt round-robin over the 8 XCDs (own L2 each): ids with equal b % 8 take one CONTIGUOUS eighth of the
     // rows, so an XCD gathers from one band of the source frame instead of all of it
-    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7u, per = nb >> 3, rem = nb & 7u;
-    const unsigned bid = (nb >= 8u) ? xcd * per + min(xcd, rem) + (blockIdx.x >> 3) : blockIdx.x;
-    const int wseg = (int)bid * 4 + wv;
+    const int wseg = (int)sn_xcd_band(blockIdx.x, gridDim.x) * 4 + wv;
     const int y = wseg / segs;
     if (y >= H) return;                                        // wave-uniform
     const int x0 = (wseg - y * segs) * (64 * PX);
