@@ -488,6 +488,33 @@ def try_load_imagenet_resnet(prefix: str):
     return None, "%s not found" % prefix
 
 
+def imagenet_expected_names(init: dict) -> list:
+    """The variables `restorer.restore` fills (train_bundle_nobm.py:185-191): everything under `stable_net/resnet/` except
+    `resnet_v2_50/conv1` (13 input channels), the `fc` head, Adam slots and `gen_theta` -- in this build's names (scope stripped)
+    every `resnet_v2_50/*` entry of a fresh parameter set but `resnet_v2_50/conv1/*`."""
+    return sorted(k for k in init if k.startswith("resnet_v2_50/") and not k.startswith("resnet_v2_50/conv1/"))
+
+
+def apply_imagenet_init(init: dict, pre: dict) -> int:
+    """Copies the warm-start variables over `init` in place; like `tf.train.Saver(vtr).restore` it FAILS on any expected variable
+    the checkpoint lacks or holds with another shape (a wrong or truncated checkpoint must not silently become training from
+    the seeded initialiser).  -> number of variables initialised."""
+    want = imagenet_expected_names(init)
+    missing = [k for k in want if k not in pre]
+    misshaped = ["%s: checkpoint %s, model %s" % (k, tuple(pre[k].shape), tuple(init[k].shape))
+                 for k in want if k in pre and tuple(pre[k].shape) != tuple(init[k].shape)]
+    if missing or misshaped:
+        def head(lst):
+            return ", ".join(lst[:8]) + (" ... (%d in all)" % len(lst) if len(lst) > 8 else "")
+        raise ValueError("tf_checkpoint: the ImageNet checkpoint does not cover the backbone: "
+                         + ("missing " + head(missing) if missing else "")
+                         + ("; " if missing and misshaped else "")
+                         + ("wrong shape " + head(misshaped) if misshaped else ""))
+    for k in want:
+        init[k] = np.asarray(pre[k], np.float32)
+    return len(want)
+
+
 def read_checkpoint(prefix: str) -> dict:
     """{name: ndarray} of a V2 bundle (`<prefix>.index`) or a V1 single-file checkpoint (`<prefix>`)."""
     fmt = checkpoint_format(prefix)

@@ -102,7 +102,8 @@ def test_cli_drivers_run(cuda, tmp_path):
                           "--no-imagenet-init"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "final loss" in out.stdout and os.path.exists(tmp_path / "m" / "model-2.npz")
+    # resuming needs NO ImageNet file (train_bundle_nobm.py:204-208: restorer.restore only in the else branch of `if args.restore`)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "train_bundle_nobm.py"), "--restore", "--iters", "4",
                           "--batch-size", "2", "--height", "64", "--width", "96", "--model-dir", str(tmp_path / "m"),
-                          "--no-imagenet-init"], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and "restoring" in out.stdout, out.stderr[-2000:]
+                          "--imagenet-ckpt", str(tmp_path / "absent.ckpt")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "restoring" in out.stdout and "warm start skipped" in out.stdout, out.stderr[-2000:]

@@ -120,3 +120,30 @@ def test_v1_checkpoint_layouts(tmp_path):
     assert C._snappy_decompress(bytes([12, (4 - 1) << 2]) + b"abcd" + bytes([((8 - 4) << 2) | 1, 4])) == b"abcdabcdabcd"
     with pytest.raises(ValueError):
         C._snappy_decompress(bytes([4, 0x01 | (0 << 2), 9]))                 # copy from before the start
+
+
+def test_imagenet_init_is_strict():
+    """`tf.train.Saver(vtr).restore` (train_bundle_nobm.py:185-191,208) fails on a missing or mis-shaped variable; so does the warm
+    start here: a truncated / foreign checkpoint must not turn into training from the seeded initialiser."""
+    from stabnet_amd import synthetic
+    from stabnet_amd.config import Config
+    init = synthetic.make_params(Config(height=64, width=64), seed=0, theta_scale=0.2)
+    want = C.imagenet_expected_names(init)
+    assert want and all(k.startswith("resnet_v2_50/") for k in want)
+    assert not any(k.startswith("resnet_v2_50/conv1/") or k.startswith("fc/") for k in want)
+    assert "resnet_v2_50/postnorm/gamma" in want and "resnet_v2_50/block4/unit_3/bottleneck_v2/conv3/biases" in want
+    pre = {k: np.full_like(init[k], 0.5) for k in want}
+    pre["resnet_v2_50/logits/weights"] = np.zeros((1, 1, 2048, 1001), np.float32)        # extras in the file are ignored
+    fresh = {k: v.copy() for k, v in init.items()}
+    assert C.apply_imagenet_init(fresh, pre) == len(want)
+    assert all(np.all(fresh[k] == 0.5) for k in want)
+    assert np.array_equal(fresh["resnet_v2_50/conv1/weights"], init["resnet_v2_50/conv1/weights"])    # stem and head untouched
+    assert np.array_equal(fresh["fc/fc_weights"], init["fc/fc_weights"])
+    short = dict(pre)
+    del short[want[3]]
+    with pytest.raises(ValueError, match="missing"):
+        C.apply_imagenet_init({k: v.copy() for k, v in init.items()}, short)
+    bad = dict(pre)
+    bad[want[5]] = np.zeros(tuple(init[want[5]].shape) + (2,), np.float32)
+    with pytest.raises(ValueError, match="wrong shape"):
+        C.apply_imagenet_init({k: v.copy() for k, v in init.items()}, bad)

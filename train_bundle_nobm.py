@@ -71,24 +71,30 @@ def main():
     N, H, W = cfg.batch_size, cfg.height, cfg.width
     init = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
     from stabnet_amd import tf_checkpoint
-    if args.no_imagenet_init:
-        pre, note = None, 'seeded initialiser (--no-imagenet-init)'
+    # train_bundle_nobm.py:204-208: `saver.restore(latest_checkpoint)` when --restore, `restorer.restore(resnet_v2_50.ckpt)` ONLY
+    # otherwise -- resuming needs no ImageNet file.  (--restore with an empty model_dir fails in the reference; here it falls
+    # back to the warm start so that the first run of a job can carry the flag.)
+    resume = latest_checkpoint(model_dir) if args.restore else None
+    if resume is not None:
+        note = 'resuming from %s: ImageNet warm start skipped' % resume
+    elif args.no_imagenet_init:
+        note = 'seeded initialiser (--no-imagenet-init)'
     else:
         pre, note = tf_checkpoint.try_load_imagenet_resnet(args.imagenet_ckpt)       # train_bundle_nobm.py:184-191,208
         if pre is None:
             # the reference's restorer.restore() raises here; silently training from scratch would be a different experiment
             raise SystemExit('train_bundle_nobm.py: cannot warm-start the backbone: %s.  Provide --imagenet-ckpt <resnet_v2_50.ckpt> '
                              '(V1 or V2 TensorFlow checkpoint) or pass --no-imagenet-init to train from the seeded initialiser.' % note)
-    if pre is not None:
-        hit = [k for k in pre if k in init and pre[k].shape == init[k].shape]
-        for k in hit:
-            init[k] = pre[k]
-        note = 'initialised %d backbone variables from %s' % (len(hit), args.imagenet_ckpt)
+        try:
+            n_hit = tf_checkpoint.apply_imagenet_init(init, pre)    # every expected variable or an error, like Saver.restore
+        except ValueError as e:
+            raise SystemExit('train_bundle_nobm.py: %s' % e)
+        note = 'initialised %d backbone variables from %s' % (n_hit, args.imagenet_ckpt)
     if rank == 0:
         print('note: ' + note)
     tr = Trainer(init, N, H, W, cfg, device=dev, process_group=pg, world_size=world)
-    if args.restore:
-        ck = latest_checkpoint(model_dir)
+    if resume is not None:
+        ck = resume
         if ck:
             z = np.load(ck)
             tr.load_state_dict({'params': tr.plan.pack({k: z[k] for k in z.files if not k.startswith('__')}),
