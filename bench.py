@@ -289,10 +289,32 @@ def _free_port():
     return p
 
 
-def visible_gpus():
-    """Devices this process could use.  torch.cuda.device_count() does not initialise the GPU on this image, so the parent
-    of launch_ranks() stays GPU-free (a process that has touched the GPU must never be replaced or re-exec'd)."""
-    return torch.cuda.device_count()
+def _kfd_gpu_nodes(root="/sys/class/kfd/kfd/topology/nodes"):
+    """GPU agents the kernel driver lists (nodes with SIMDs; CPU nodes have simd_count 0), read from sysfs: no HIP / HSA call."""
+    n = 0
+    for d in sorted(os.listdir(root)):
+        with open(os.path.join(root, d, "properties")) as f:
+            props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    return n
+
+
+def visible_gpus(environ=None, kfd_root="/sys/class/kfd/kfd/topology/nodes"):
+    """Devices this process could use, WITHOUT touching the GPU runtime: the KFD topology in sysfs, narrowed by the
+    *_VISIBLE_DEVICES lists (comma-separated indices or UUIDs; an empty list hides every device).  Only when sysfs cannot be read
+    does it fall back to torch.cuda.device_count(), which may open the driver -- harmless for launch_ranks(), whose rule is
+    'children are started with subprocess.Popen, the parent is never replaced or re-exec'd'."""
+    env = os.environ if environ is None else environ
+    try:
+        n = _kfd_gpu_nodes(kfd_root)
+    except (OSError, ValueError):
+        return torch.cuda.device_count()
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
 
 
 def launch_command(n, argv, env, ndev):

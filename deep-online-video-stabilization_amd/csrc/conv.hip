@@ -270,6 +270,15 @@ static int launch_ring(const ConvArgs& a, hipStream_t st) {
 // Two groups with the fragment prologue (conv_ring_f32_kernel<0, 0, 2, 1>): the 1x1 layers that carry a BN + ReLU prologue AND
 // split K in two (the block-3 conv1 layers of a 720p frame, K = 1024: register-staged kernel x 2 slices + slabs + a reduce launch
 // before) as one 8-wave workgroup per tile.
+// The PRO form fetches a step's scales AND shifts with one DMA instruction: the shifts are addressed as an unsigned 32-bit byte
+// offset from the (running) scale pointer.  Callers of the public operators pass two independent pointers: a shift vector below
+// the scales, or 4 GiB or more above them, must take the register-staged kernel (which dereferences both pointers).  Plan time
+// (pointers not bound yet): true -- the launch decides again with the real pointers.
+static bool ring_pro_vectors_ok(const ConvArgs& a) {
+    if (a.in_scale == nullptr || a.in_shift == nullptr) return true;
+    const long d = (long)(a.in_shift - a.in_scale);                   // floats
+    return d >= 0 && d < (1L << 30);
+}
 static bool ring_pro_geometry(const ConvArgs& a, bool has_prologue) {
     static const int on = env_int("STABNET_CONV_RING_PRO", 1);
     if (g_ring < 0) g_ring = env_int("STABNET_CONV_RING", 1);
@@ -283,7 +292,7 @@ static int conv_kgroups(const ConvArgs& a, bool ring, bool has_prologue) {
     const int steps = conv_total_steps(a);
     if (a.steps_per_split * a.splitk != steps) return 1;
     if (ring && a.splitk == 3 && !a.rowrun) return 3;
-    if (on2 && !ring && a.splitk == 2 && ring_pro_geometry(a, has_prologue)) return 2;
+    if (on2 && !ring && a.splitk == 2 && ring_pro_geometry(a, has_prologue) && ring_pro_vectors_ok(a)) return 2;
     return 1;
 }
 
@@ -322,7 +331,8 @@ static bool ring_pro_eligible(const ConvArgs& a) {
     static const int on = env_int("STABNET_CONV_RING_PRO", 1);
     if (g_ring < 0) g_ring = env_int("STABNET_CONV_RING", 1);
     return on && g_ring && !g_bf16_operands && !g_force_bk16 && a.in_scale != nullptr && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 &&
-           a.up == 1 && a.Cin % 32 == 0 && a.out_scale == nullptr && a.out_floor == nullptr && !a.rowrun && a.x_ld == a.Cin;
+           a.up == 1 && a.Cin % 32 == 0 && a.out_scale == nullptr && a.out_floor == nullptr && !a.rowrun && a.x_ld == a.Cin &&
+           ring_pro_vectors_ok(a);
 }
 static int launch_ring_pro(ConvArgs a, long delta, hipStream_t st) {
     if (g_ring_wgs == 0) {

@@ -499,6 +499,10 @@ int wgrad_launch_g(int T, const float* const* x, const float* const* dy, float* 
     a.rowrun = rowrun ? 1 : 0;
     SN_REQUIRE(T == 1 || T == 2, "wgrad: 1 or 2 towers");
     SN_REQUIRE((rowrun || Cin % 4 == 0) && Cout % 4 == 0, "wgrad: channel counts must be multiples of 4");
+    // the slab reduction adds into the gradients 16 B per thread (float4 read-modify-write), weights and bias sums alike
+    SN_REQUIRE(((size_t)sn_float_at(dw_base, dw_off) & 15) == 0 && (bias_off < 0 || ((size_t)sn_float_at(dw_base, bias_off) & 15) == 0) &&
+                   (bias_off2 < 0 || ((size_t)sn_float_at(dw_base, bias_off2) & 15) == 0),
+               "wgrad: dw and d_bias must be 16-byte aligned");
     SN_REQUIRE((long)a.M * Cout < (1L << 31) && ((long)N * (H + 2 * pad) + 1) * (W + 2 * pad) * Cin < (1L << 31),
                "wgrad: tensors must have < 2^31 elements");
     const int splits = wgrad_splits(Cout, a.K, a.M, &a.rows_per_split);

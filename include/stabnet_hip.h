@@ -228,7 +228,8 @@ int stabnet_mesh_losses(const float* theta, const float* d_pts2_warp, int N, int
 
 /* dW (OHWI, ACCUMULATED into, not zeroed) += d conv2d / d weights.  x: forward input; (in_scale,in_shift): the forward's
  * folded-BN + ReLU prologue (both or NULL); dy [N,Ho,Wo,Cout].  Exact float32 MFMA; the pixel range is split over
- * workgroups whose partial tiles go to slabs in `workspace` and are added in split order (reproducible, no atomics). */
+ * workgroups whose partial tiles go to slabs in `workspace` and are added in split order (reproducible, no atomics).
+ * dw (and d_bias below) must be 16-byte aligned: the slab reduction updates them 16 B at a time (STABNET_ERR_BAD_ARG otherwise). */
 size_t stabnet_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int stabnet_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* in_scale, const float* in_shift,
                          int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* workspace,

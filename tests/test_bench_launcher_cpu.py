@@ -74,3 +74,19 @@ def test_main_launches_before_any_gpu_call_and_rejects_a_mismatched_world(monkey
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "must agree" in str(e.value)
+
+
+def test_visible_gpus_reads_sysfs_not_the_runtime(monkeypatch, tmp_path):
+    """the launcher parent counts devices from the KFD topology (sysfs) and the *_VISIBLE_DEVICES lists; the GPU
+    runtime is only the fallback when sysfs is unreadable."""
+    for i, simd in enumerate([0, 0, 256, 256, 256]):                     # two CPU nodes, three GPU agents
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simd == 0 else 0, simd))
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: pytest.fail("runtime touched"))
+    assert bench.visible_gpus({}, str(tmp_path)) == 3
+    assert bench.visible_gpus({"HIP_VISIBLE_DEVICES": "0,2"}, str(tmp_path)) == 2
+    assert bench.visible_gpus({"ROCR_VISIBLE_DEVICES": "1", "HIP_VISIBLE_DEVICES": "0,1,2"}, str(tmp_path)) == 1
+    assert bench.visible_gpus({"CUDA_VISIBLE_DEVICES": ""}, str(tmp_path)) == 0
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 5)
+    assert bench.visible_gpus({}, str(tmp_path / "absent")) == 5           # no sysfs: the documented fallback

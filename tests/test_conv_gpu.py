@@ -177,3 +177,35 @@ def test_two_k_groups_with_prologue(cuda, N, H, W, Cin, Cout, bias, res, relu, o
         assert np.abs(got - want).max() <= (4e-5 if out_bn else 2e-5) * scale
     assert np.array_equal(got2, got2b)
     assert np.abs(got2 - got1).max() <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("split", [1, 2])
+def test_prologue_vectors_in_any_address_order(cuda, split):
+    """The ABI takes in_scale and in_shift as two independent pointers.  The LDS-DMA kernel's fragment-prologue form reaches the
+    shifts through a 32-bit unsigned offset from the scales, which only exists when the shifts lie 0..4 GiB above them: any other
+    placement must take the register-staged kernel and give the same numbers (it used to wrap -> out-of-bounds read)."""
+    from stabnet_amd import _lib, ops
+    N, H, W, Cin, Cout = 1, 45, 80, 256, 64
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((1, 1, Cin, Cout)) * np.sqrt(2.0 / Cin)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, Cin).astype(np.float32)
+    sh = (rng.standard_normal(Cin) * 0.3).astype(np.float32)
+    want = O.conv2d(np.maximum(x * sc + sh, 0).astype(np.float32), w, 1, ((0, 0), (0, 0)), None)
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(cuda)
+    buf = torch.empty(4 * Cin, dtype=torch.float32, device=cuda)
+    lo, hi = buf[:Cin], buf[3 * Cin:]
+    L = _lib.lib()
+    got = {}
+    try:
+        L.stabnet_conv_tuning_override(2, split)
+        for name, (s_t, h_t) in {"shift_above": (lo, hi), "shift_below": (hi, lo)}.items():
+            s_t.copy_(t(sc)); h_t.copy_(t(sh))
+            assert (h_t.data_ptr() > s_t.data_ptr()) == (name == "shift_above")
+            got[name] = ops.conv2d(t(x), t(ops.pack_conv_weight(w)), None, s_t, h_t, None, 1, 1, 0, False).cpu().numpy()
+    finally:
+        L.stabnet_conv_tuning_override(-1, -1)
+    scale = np.abs(want).max()
+    for g in got.values():
+        assert np.isfinite(g).all() and np.abs(g - want).max() <= 2e-5 * scale
+    assert np.abs(got["shift_above"] - got["shift_below"]).max() <= 1e-5 * scale    # two kernels, float32 summation order only
