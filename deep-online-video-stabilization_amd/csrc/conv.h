@@ -56,6 +56,13 @@ struct ConvPair { int m_tower, x_tower_floats /* N*H*W*Cin of one tower's input 
 bool conv_pair_supported(const ConvArgs& a);
 int conv_launch_pair(const ConvArgs& a, const ConvPair& pr, hipStream_t st, Prof* prof = nullptr);
 
+// A bottleneck unit's 3x3 `conv2` and 1x1 `conv3` as ONE launch (conv_b2b_kernel.h): c2 / c3 are the two planned convolutions as
+// conv_launch() would take them (c2.out_scale / out_shift = the folded BN between them, ReLU implied; c2.y is not written).
+// conv_b2b_supported(): the geometry the kernel takes (3x3 / pad 1 over Cin == Cout == 64 or 128, no bias / residual / prologue;
+// 1x1 stride-1 c3 over the same pixels with Cout a multiple of c2.Cout, no prologue) -- pointers are not looked at.
+bool conv_b2b_supported(const ConvArgs& c2, const ConvArgs& c3);
+int conv_b2b_launch(const ConvArgs& c2, const ConvArgs& c3, hipStream_t st, Prof* prof = nullptr);
+
 // Exact unsigned division by an invariant divisor d >= 1 for numerators n < 2^31 (Granlund-Montgomery round-up form):
 //   l = ceil(log2 d), mul = floor(2^32 (2^l - d) / d) + 1, n / d = (mulhi(mul, n) + n) >> l.
 // Three instructions instead of the ~40 of a software 32-bit division; the kernels' per-tile index setup is VALU work

@@ -22,6 +22,7 @@
 
 #include "conv_kernel.h"
 #include "conv_ring_kernel.h"
+#include "conv_b2b_kernel.h"
 
 // Sums the split-K partial slabs in a fixed order and applies the epilogue.  One thread per 4 channels.
 template <int PAIR>
@@ -470,6 +471,52 @@ int conv_launch_pair(const ConvArgs& a, const ConvPair& pr, hipStream_t st, Prof
     return STABNET_OK;
 }
 
+// ---- conv2 (3x3) -> conv3 (1x1) back to back (conv_b2b_kernel.h) ------------------------------------------
+bool conv_b2b_supported(const ConvArgs& c2, const ConvArgs& c3) {
+    static const int on = env_int("STABNET_CONV_B2B", 1);
+    if (g_ring < 0) g_ring = env_int("STABNET_CONV_RING", 1);
+    const bool g2 = c2.KH == 3 && c2.KW == 3 && c2.pad == 1 && c2.up == 1 && !c2.rowrun && (c2.stride == 1 || c2.stride == 2) &&
+                    c2.Cin == c2.Cout && (c2.Cout == 64 || c2.Cout == 128) && c2.in_scale_expected == 0 && c2.in_scale == nullptr;
+    const bool g3 = c3.KH == 1 && c3.KW == 1 && c3.pad == 0 && c3.stride == 1 && c3.up == 1 && !c3.rowrun && c3.Cin == c2.Cout &&
+                    (c3.x_ld == 0 || c3.x_ld == c3.Cin) && c3.Cout % c2.Cout == 0 && c3.N == c2.N && c3.H == c2.Ho && c3.W == c2.Wo &&
+                    c3.in_scale_expected == 0 && c3.in_scale == nullptr;
+    return on && g_ring && g2 && g3;
+}
+
+int conv_b2b_launch(const ConvArgs& c2, const ConvArgs& c3, hipStream_t st, Prof* prof) {
+    SN_REQUIRE(conv_b2b_supported(c2, c3), "conv b2b: unsupported geometry");
+    SN_REQUIRE(c2.div_hw_mul != 0 && c3.div_hw_mul != 0 && c2.M == c3.M, "conv b2b: conv_plan() not called on both convolutions");
+    SN_REQUIRE(c2.x && c2.w && c3.w && c3.y && c2.out_scale && c2.out_shift, "conv b2b: null pointer");
+    SN_REQUIRE(c2.bias == nullptr && c2.residual == nullptr, "conv b2b: the 3x3 convolution takes no bias / residual");
+    SN_REQUIRE(g_bf16_operands == 0, "conv b2b: fp32 only");
+    const int cus = device_cus();
+    if (cus <= 0) {
+        stabnet_set_error("conv: cannot read the CU count");
+        return STABNET_ERR_LAUNCH;
+    }
+    B2bArgs P;
+    P.c2 = c2;
+    P.c3 = c3;
+    P.c3.splitk = 1;                                                  // the accumulators handed to the epilogue are the full sum
+    P.c3.steps_per_split = conv_total_steps(c3);
+    P.epi_vmem = 4 + (c3.residual ? 4 : 0) + (c3.bias ? 1 : 0) + (c3.out_scale ? 2 : 0) + ((c3.out_scale && c3.out_floor) ? 1 : 0);
+    const int tiles_m = cdiv(c2.M, 64);
+    const bool rec = prof != nullptr && prof->begin(st);
+    if (c2.Cout == 64) {
+        static const int wgs = env_int("STABNET_CONV_B2B_WGS_PER_CU", 2);     // 80 KB of LDS each
+        conv_b2b_f32_kernel<2><<<std::min(tiles_m, wgs * cus), 256, 0, st>>>(P);
+    } else {
+        conv_b2b_f32_kernel<4><<<std::min(tiles_m, cus), 512, 0, st>>>(P);    // 136 KB of LDS
+    }
+    if (rec) prof->end(st, PK_KERNEL_CONV_B2B + (c2.Cout == 128 ? 1 : 0),
+                       2.0 * c2.M * ((double)c2.K * c2.Cout + (double)c3.K * c3.Cout),
+                       4.0 * ((double)c2.N * c2.H * c2.W * c2.Cin + (double)c2.K * c2.Cout + (double)c3.K * c3.Cout +
+                              (double)c3.M * c3.Cout * (c3.residual ? 2 : 1)),
+                       c2.M, c3.Cout, c2.K + c3.K, 1);
+    SN_LAUNCH_CHECK("conv_b2b_f32_kernel");
+    return STABNET_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 static int fill_args(ConvArgs& a, const float* x, const float* w, const float* bias, const float* in_scale,
                      const float* in_shift, const float* residual, int res_H, int res_W, int res_stride, float* y,
@@ -567,6 +614,36 @@ int stabnet_conv2d_fwd_ex(const float* x, const float* w_ohwi, const float* bias
     a.out_scale = out_scale;
     a.out_shift = out_shift;
     return conv_launch(a, (hipStream_t)stream);
+}
+
+/* conv2 (3x3, pad 1, stride 1 | 2, C -> C channels, C = 64 | 128, no bias) -> folded BN (mid_scale, mid_shift) + ReLU -> conv3
+ * (1x1, C -> Cout, Cout % C == 0) with conv2d_fwd_ex's epilogue (bias, residual, out_scale / out_shift, relu_out) as ONE launch:
+ * the tail of a slim bottleneck_v2 unit (s_net_bundle_nobm.py:252-253); the C-channel intermediate never reaches memory.
+ * x [N,H,W,C] with x_ld floats between pixels (0 = C); y [N,Ho,Wo,Cout]; residual read at (oy*res_stride, ox*res_stride) with
+ * res_ld floats between pixels (0 = Cout).  STABNET_ERR_BAD_ARG for other geometries. */
+int stabnet_conv3x3_conv1x1_fwd(const float* x, int x_ld, const float* w2_ohwi, const float* mid_scale, const float* mid_shift,
+                                const float* w3_ohwi, const float* bias3, const float* residual, int res_H, int res_W,
+                                int res_stride, int res_ld, const float* out_scale, const float* out_shift, float* y, int N, int H,
+                                int W, int C, int Cout, int stride, int relu_out, void* stream) {
+    SN_REQUIRE(x && w2_ohwi && mid_scale && mid_shift && w3_ohwi && y, "conv3x3_conv1x1_fwd: null pointer");
+    SN_REQUIRE((out_scale == nullptr) == (out_shift == nullptr), "conv3x3_conv1x1_fwd: out_scale and out_shift go together");
+    ConvArgs c2, c3;
+    int rc = fill_args(c2, x, w2_ohwi, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, nullptr, N, H, W, C, C, 3, 3, stride, 1, 1);
+    if (rc) return rc;
+    c2.x_ld = x_ld;
+    (void)conv_plan(c2);
+    c2.out_scale = mid_scale;
+    c2.out_shift = mid_shift;
+    rc = fill_args(c3, nullptr, w3_ohwi, bias3, nullptr, nullptr, residual, res_H, res_W, res_stride, y, N, c2.Ho, c2.Wo, C, Cout,
+                   1, 1, 1, 0, relu_out);
+    if (rc) return rc;
+    c3.res_ld = res_ld;
+    (void)conv_plan(c3);
+    c3.out_scale = out_scale;
+    c3.out_shift = out_shift;
+    SN_REQUIRE(conv_b2b_supported(c2, c3), "conv3x3_conv1x1_fwd: C must be 64 or 128, Cout a multiple of C, stride 1 or 2");
+    g_bf16_operands = 0;
+    return conv_b2b_launch(c2, c3, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,477 @@
+// Back-to-back GEMM: a bottleneck unit's 3x3 `conv2` and its 1x1 `conv3` as ONE launch (gfx950, exact float32 MFMA).
+//
+// slim's bottleneck_v2 (called at s_net_bundle_nobm.py:252-253): residual = conv3(relu(bn2(conv2(a1)))) with conv2 3x3 over
+// d_b = 64 / 128 channels and conv3 1x1 to 4 d_b channels (+ bias + shortcut).  Launched one after the other (conv_ring_kernel.h)
+// the `conv2` output makes a round trip through memory (14.7 / 7.4 MB at 720p) and the `conv3` launch -- two or four K-steps
+// of matrix work per 16 KB of epilogue -- is bounded by its stores and by launch fill / drain.  Here a
+// workgroup owns a 64-row M tile over the FULL width of conv2 (N = d_b = 32 NWN), so the activated conv2 tile never leaves the CU:
+//
+//   phase 0 (S2 = 9 NWN K-steps): the ring kernel's MODE 1 loop -- A [64][32] and B [32 NWN][32] stages by LDS-DMA, 3 stages in
+//            flight -- with the MFMA operands SWAPPED: acc^T = W2 * A^T.  In the transposed C/D map a lane holds pixel row
+//            m = lane & 31 and, in registers 4q .. 4q+3, the FOUR CONSECUTIVE channels n = 8q + 4h .. (h = lane >> 5): exactly one
+//            16-byte chunk of the A-operand stage layout.  The tile's end applies bn2 + ReLU on the accumulators and PARKS them
+//            with four ds_write_b128 per lane as NWN ready-made A stages ([ks][64 rows][32 floats], same XOR swizzle): no
+//            transposition pass, no scratch.
+//   phase 1 (S3 = (Cout3 / 32 NWN) * NWN steps): conv3 walks its N in chunks of 32 NWN channels, NWN K-steps each.  A fragments
+//            come from the park, B stages (W3 rows of the chunk, [32 NWN][32]) from the SAME ring -- they do not depend on phase
+//            0, so the producer side streams them three stages ahead like any other stage, across the phase and tile boundaries.
+//            Each chunk ends with the ring kernel's full epilogue (bias + residual + the next unit's folded BN + ReLU / floor,
+//            16 B per lane through a wave-private LDS transpose).
+//
+// Differences from conv_ring_kernel.h that matter for speed:
+//   * the epilogue scratch is NOT a ring slot (dedicated 4 KB per wave): a chunk's end neither stalls the producer nor needs the
+//     extra barrier, which matters when a "tile" is only NWN = 2 / 4 steps long;
+//   * waits are counted past the epilogue: `s_waitcnt vmcnt(N)` with N = DMAs of the youngest stage + the VMEM operations of the
+//     chunk epilogue issued behind it (P.epi_vmem, interior tiles only), so the stores of chunk c drain under the MFMAs of
+//     chunk c + 1 instead of being waited for at its first barrier.
+//   NWN = 2: d_b = 64 (block 1), 4 waves, 80 KB of LDS (ring 48 + park 16 + scratch 16): two workgroups per CU.
+//   NWN = 4: d_b = 128 (block 2), 8 waves (2 x 4 of 32 x 32), 136 KB (72 + 32 + 32): one workgroup per CU.
+#pragma once
+#include "conv_ring_kernel.h"
+
+struct B2bArgs {
+    ConvArgs c2;     // the 3x3 convolution (pad 1, stride 1 or 2, Cin == Cout == 32 NWN, no bias, no residual, no prologue):
+                     //   x / x_ld / w / geometry as for conv_ring_f32_kernel<1>; out_scale / out_shift = folded bn2 (ReLU implied); y unused
+    ConvArgs c3;     // the 1x1 convolution of the parked tile (Cin == c2.Cout, M == c2.M): w, bias, residual (+ res_*), out_scale /
+                     //   out_shift / out_floor / relu_out, y; planned by conv_plan() (M, div_*, res_ld), splitk == 1
+    int epi_vmem;    // VMEM operations one conv3 chunk epilogue issues per wave on an INTERIOR tile (b2b_chunk_epilogue: 4 stores +
+                     //   4 residual loads + bias + 2 for out_scale / out_shift + 1 for out_floor); must not exceed the real count
+};
+
+#ifndef B2B_STAMP
+#define B2B_STAMP 0            // probe-only: per-workgroup s_memrealtime stamps (tools/b2b_probe.hip)
+#endif
+#if B2B_STAMP
+__device__ unsigned long long g_b2b_stamps[2048 * 8];
+#define B2B_STAMP_AT(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_b2b_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define B2B_STAMP_AT(i) do { } while (0)
+#endif
+
+// conv3's chunk epilogue: conv_epilogue<1, 1> (conv_kernel.h) -- same arithmetic, same order: + bias, + residual, * out_scale +
+// out_shift, floor / ReLU -- restated so that the number of vector-memory operations a wave issues is FIXED by the launch's flags
+// (the kernel counts them in its `s_waitcnt vmcnt`, see wait_next_stage): every per-channel vector is one 16-byte load of an
+// ext_vector (HIP's float4 struct is split by the compiler into four branchy 4-byte loads when the load is conditional).
+// Vector-memory operations of an interior tile: 4 stores + (residual: 4) + (bias: 1) + (out_scale, out_shift: 2) + (floor: 1).
+__device__ __forceinline__ void b2b_chunk_epilogue(const f32x16& a, const ConvArgs& p, int mw0, int nw0, int lane, unsigned scratch) {
+    const bool has_res = p.residual != nullptr, has_obn = p.out_scale != nullptr, has_bias = p.bias != nullptr;
+    const bool has_floor = has_obn && p.out_floor != nullptr, relu = p.relu_out != 0;
+    const bool res_plain = p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo;
+    const unsigned wr = scratch + (unsigned)(((4 * (lane >> 5)) * 32 + (lane & 31)) * 4);   // C/D role
+    const int rrow = lane >> 3, rc4 = (lane & 7) * 4;                                        // row-major role: rows rrow + 8q
+    const unsigned rd = scratch + (unsigned)((rrow * 32 + rc4) * 4);
+    const int n = nw0 + rc4;                                                                 // (< Cout: chunks are whole)
+    int mrow[4];
+    f32x4 rv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        mrow[q] = mw0 + rrow + 8 * q;
+        if (has_res) {
+            const int m = min(mrow[q], p.M - 1);
+            unsigned roff;
+            if (res_plain) {
+                roff = (unsigned)(m * p.res_ld);
+            } else {
+                const int img = sn_fastdiv(m, p.div_hw_mul, p.div_hw_shift);
+                const int rr = m - img * (p.Ho * p.Wo);
+                const int oy = sn_fastdiv(rr, p.div_w_mul, p.div_w_shift), ox = rr - oy * p.Wo;
+                roff = (unsigned)(((img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.res_ld);
+            }
+            rv[q] = *reinterpret_cast<const f32x4*>(p.residual + (roff + (unsigned)n));
+        }
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bv = zero4, os = zero4, ob = zero4, fl = zero4;
+    if (has_bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (has_obn) { os = *reinterpret_cast<const f32x4*>(p.out_scale + n); ob = *reinterpret_cast<const f32x4*>(p.out_shift + n); }
+    if (has_floor) fl = *reinterpret_cast<const f32x4*>(p.out_floor + n);
+    SN_EPI_W(0); SN_EPI_W(1); SN_EPI_W(2); SN_EPI_W(3); SN_EPI_W(4); SN_EPI_W(5); SN_EPI_W(6); SN_EPI_W(7);
+    SN_EPI_W(8); SN_EPI_W(9); SN_EPI_W(10); SN_EPI_W(11); SN_EPI_W(12); SN_EPI_W(13); SN_EPI_W(14); SN_EPI_W(15);
+    f32x4 t[4];
+    SN_EPI_R(0, t[0]); SN_EPI_R(1, t[1]); SN_EPI_R(2, t[2]); SN_EPI_R(3, t[3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])::"memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v = t[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e] + bv[e];
+            if (has_res) x += rv[q][e];
+            if (has_obn) x = __builtin_fmaf(x, os[e], ob[e]);
+            if (has_floor) x = fmaxf(x, fl[e]);
+            else if (relu) x = fmaxf(x, 0.f);
+            v[e] = x;
+        }
+        if (mrow[q] < p.M) *reinterpret_cast<f32x4*>(p.y + ((size_t)mrow[q] * p.Cout + n)) = v;
+    }
+}
+
+template <int NWN /* 32-column wave tiles across conv2's N: 2 (d_b = 64) or 4 (d_b = 128) */>
+__global__ __launch_bounds__(128 * NWN) void conv_b2b_f32_kernel(const B2bArgs P) {
+    static_assert(NWN == 2 || NWN == 4, "d_b = 64 or 128");
+    constexpr int NW = 2 * NWN;                            // waves: 2 (M) x NWN (N) of 32 x 32
+    constexpr int BM = 64, BK = 32, BN2 = 32 * NWN;
+    constexpr int A_BYTES = BM * BK * 4;                   // 8 KiB
+    constexpr int B_BYTES = BN2 * BK * 4;                  // 4 KiB x NWN
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int PARK_BYTES = NWN * A_BYTES;              // the activated conv2 tile as NWN A stages
+    constexpr int SCR_BYTES = NW * SN_EPI_WAVE_BYTES;
+    constexpr int A_PER_WAVE = 8 / NW;                     // A DMA instructions (8 rows each) per wave and conv2 stage: 2 / 1
+    constexpr int CNT2 = A_PER_WAVE + 2, CNT3 = 2;         // DMAs per wave in a conv2 / conv3 stage
+    __shared__ __attribute__((aligned(16))) float lds[(3 * STAGE_BYTES + PARK_BYTES + SCR_BYTES) / 4];
+
+    const ConvArgs& p = P.c2;
+    const ConvArgs& q3 = P.c3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    B2B_STAMP_AT(0);
+    const int tiles_m = (p.M + BM - 1) / BM;
+    int t_first = blockIdx.x, t_stride = gridDim.x, t_end = tiles_m;
+    if (p.xcd_swizzle && gridDim.x >= 8) {                 // workgroups of one XCD take one contiguous run of M tiles (conv_ring_kernel.h)
+        const int x = blockIdx.x & 7, Gt = (int)gridDim.x;
+        t_stride = (Gt - x + 7) >> 3;
+        const int before = x * (Gt >> 3) + min(x, Gt & 7);
+        const int lo = (int)((long)tiles_m * before / Gt), hi = (int)((long)tiles_m * (before + t_stride) / Gt);
+        t_first = lo + (blockIdx.x >> 3);
+        t_end = hi;
+    }
+    const int S2 = p.KH * p.KW * NWN;                      // conv2 K-steps (Cin == BN2: NWN per tap)
+    const int S3 = (q3.Cout / BN2) * NWN;                  // conv3: chunks of BN2 output channels x NWN K-steps
+    const int T = S2 + S3;
+    int my_tiles = 0;
+    for (int t = t_first; t < t_end; t += t_stride) ++my_tiles;
+    int remaining = my_tiles * T;
+    if (remaining == 0) return;
+
+    const unsigned lds_base = (unsigned)(size_t)(sn_lds_ptr_t)lds;
+    const unsigned park_base = lds_base + 3u * STAGE_BYTES;
+    const unsigned scr_base = park_base + (unsigned)PARK_BYTES + (unsigned)wave * (unsigned)SN_EPI_WAVE_BYTES;
+
+    // ---- bn2 (+ ReLU) of the transposed accumulators: channel n = wn*32 + 8q + 4h + e lives in register 4q + e
+    f32x4 sc[4], sh[4];
+    {
+        const int n_base = wn * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const float4 a = *reinterpret_cast<const float4*>(p.out_scale + n_base + 8 * qq);
+            const float4 b = *reinterpret_cast<const float4*>(p.out_shift + n_base + 8 * qq);
+            sc[qq] = f32x4{a.x, a.y, a.z, a.w};
+            sh[qq] = f32x4{b.x, b.y, b.z, b.w};
+        }
+        // (landed before the first DMA is issued: the compiler does not see the inline-asm DMAs and must not carry these loads as
+        //  pending into the loop, where its own wait would drain the ring)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) asm volatile("" : "+v"(sc[qq]), "+v"(sh[qq]));
+    }
+
+    // ---- DMA lane roles: one instruction = 8 tile rows x 128 B; lane l -> row 8g + (l >> 3), 16-B chunk l & 7
+    const int rr = lane >> 3, cp = lane & 7;
+    const int ld = p.x_ld;
+    const int pad_off = (p.pad * p.W + p.pad) * ld;
+    const int row_jump = (p.W - p.KW) * ld;
+    const float* const zero_page = g_conv_zero_page;
+
+    // ---- producer state
+    int pt = t_first;                                      // tile whose stages are being issued; >= t_end: exhausted
+    int ps = 0;                                            // stage index inside the tile: [0, S2) conv2, [S2, T) conv3
+    unsigned a_voff[A_PER_WAVE];
+    unsigned long long a_mask[A_PER_WAVE];
+    unsigned w2_voff[2], w3_voff[2];
+    int l_tap = 0, l_c0 = 0, l_kw = 0;
+    const float *xb = p.x, *wb = p.w;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {                          // B rows of this wave: 8 (wave + NW t) + rr, the same in every tile
+        const int row = 8 * (wave + NW * t) + rr;
+        const int cl = cp ^ ((row >> 1) & 7);
+        w2_voff[t] = 4u * (unsigned)(row * p.K + cl * 4);
+        w3_voff[t] = 4u * (unsigned)(row * BN2 + cl * 4);
+    }
+    auto producer_setup = [&]() {
+        const int m0 = pt * BM;
+#pragma unroll
+        for (int t = 0; t < A_PER_WAVE; ++t) {
+            const int row = 8 * (wave + NW * t) + rr;
+            const int cl = cp ^ ((row >> 1) & 7);
+            const int m = m0 + row;
+            const int mc = min(m, p.M - 1);
+            const int img = sn_fastdiv(mc, p.div_hw_mul, p.div_hw_shift);
+            const int r = mc - img * (p.Ho * p.Wo);
+            const int oy = sn_fastdiv(r, p.div_w_mul, p.div_w_shift), ox = r - oy * p.Wo;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            a_voff[t] = 4u * (unsigned)(((img * p.H + iy0 + p.pad) * p.W + ix0 + p.pad) * ld + cl * 4);
+            unsigned long long mk = 0;
+            if (m < p.M) {
+                const int kh_lo = max(0, -iy0), kh_hi = min(p.KH, p.H - iy0);
+                const int kw_lo = max(0, -ix0), kw_hi = min(p.KW, p.W - ix0);
+                if (kh_hi > kh_lo && kw_hi > kw_lo) {
+                    const unsigned long long rowbits = ((1ull << (kw_hi - kw_lo)) - 1ull) << kw_lo;
+                    for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * p.KW);
+                }
+            }
+            a_mask[t] = mk;
+        }
+        ps = 0; l_tap = 0; l_c0 = 0; l_kw = 0;
+        xb = p.x - pad_off;
+        wb = p.w;
+    };
+    const unsigned dma_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)wave * 1024u));
+    auto dma16 = [&](const float* base_, unsigned voff_bytes, unsigned lds_byte) {
+        const unsigned long long b64 = (unsigned long long)(size_t)base_;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+        const float* base = reinterpret_cast<const float*>((size_t)(((unsigned long long)hi << 32) | lo));
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(base), "s"(lds_byte) : "memory", "m0");
+    };
+    auto issue_a = [&](int slot, int t) {                  // conv2 stages only
+        if (pt >= t_end || ps >= S2) return;
+        const unsigned lds_byte = dma_base + (unsigned)(slot * STAGE_BYTES + t * NW * 1024);
+        // out-of-frame taps read the zero page: a per-lane choice between two unrelated addresses needs the 64-bit form
+        const float* src = ((a_mask[t] >> l_tap) & 1ull) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(xb) + a_voff[t]) : zero_page;
+        __builtin_amdgcn_global_load_lds((sn_gbl_ptr_t)src, (sn_lds_ptr_t)(size_t)lds_byte, 16, 0, 0);
+    };
+    auto issue_b = [&](int slot, int t) {
+        if (pt >= t_end) return;
+        const unsigned lds_byte = dma_base + (unsigned)(slot * STAGE_BYTES + A_BYTES + t * NW * 1024);
+        dma16(wb, ps < S2 ? w2_voff[t] : w3_voff[t], lds_byte);
+    };
+    auto issue_advance = [&]() {
+        if (pt >= t_end) return;
+        ++ps;
+        if (ps == T) {
+            pt += t_stride;
+            if (pt < t_end) producer_setup();
+            return;
+        }
+        if (ps > S2) {                                     // conv3: next K-step of the chunk, or the next chunk's rows
+            const int j = ps - S2;
+            wb = q3.w + (size_t)(j / NWN) * (BN2 * BN2) + (j % NWN) * BK;
+            return;
+        }
+        if (ps == S2) { wb = q3.w; return; }               // conv2 -> conv3: chunk 0, K-step 0
+        xb += BK;
+        wb += BK;
+        l_c0 += BK;
+        if (l_c0 == p.Cin) {
+            l_c0 = 0;
+            ++l_tap;
+            xb += ld - p.Cin;
+            if (++l_kw == p.KW) { l_kw = 0; xb += row_jump; }
+        }
+    };
+    auto issue_part = [&](int slot, int part) {
+        if (part == 0) issue_a(slot, 0);
+        else if (part == 1) { if constexpr (A_PER_WAVE == 2) issue_a(slot, 1); issue_b(slot, 0); }
+        else if (part == 2) issue_b(slot, 1);
+        else issue_advance();
+    };
+    auto issue = [&](int slot) { issue_part(slot, 0); issue_part(slot, 1); issue_part(slot, 2); issue_part(slot, 3); };
+
+    // ---- consumer state
+    int ct = t_first;                                      // tile being computed
+    int cs = 0;                                            // its step index: [0, S2) conv2, [S2, T) conv3
+    int epi_prev = 0, epi_prev2 = 0;                       // VMEM operations of the epilogues issued at the end of the previous step / the one before
+
+    // ---- fragment read addresses (LDS bytes): lane (i = lane & 31, h = lane >> 5) reads logical chunk 2kk + h of its row
+    unsigned a_frag[4], b_frag[4], p_frag[4], park_wr[4];
+    {
+        const int ra = wm * 32 + (lane & 31), rb = wn * 32 + (lane & 31), h = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const unsigned rel = 4u * (unsigned)(ra * BK + (((2 * kk + h) ^ ((ra >> 1) & 7)) << 2));
+            a_frag[kk] = lds_base + rel;
+            p_frag[kk] = park_base + rel;
+            park_wr[kk] = park_base + (unsigned)(wn * A_BYTES) + rel;     // accumulator quad q = kk: K-step wn of the parked tile
+            b_frag[kk] = lds_base + (unsigned)A_BYTES + 4u * (unsigned)(rb * BK + (((2 * kk + h) ^ ((rb >> 1) & 7)) << 2));
+        }
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    producer_setup();
+
+    // Fragment reads / waits / MFMAs: the ring kernel's discipline (inline asm LDS reads on pinned registers, explicit lgkmcnt
+    // waits tied to the fragment registers, every non-MFMA instruction right behind one MFMA).
+#define B2B_RD(dst, reg, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=" reg(dst) : "v"(addr), "n"(off))
+#define B2B_WAIT0() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA0(a0), "+" SN_RB0(b0))
+#define B2B_WAIT1() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA1(a1), "+" SN_RB1(b1))
+#define B2B_MF(a, b, c)  do { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.c, b.c, acc, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define B2B_MFT(a, b, c) do { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.c, a.c, acc, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define B2B_BARRIER() do { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+    // (SN_RA0 .. SN_RB1: the pinned fragment registers v[100:115], defined by conv_ring_kernel.h)
+    // `s_waitcnt vmcnt` takes an immediate: any value <= n is correct (stricter), so n is rounded down to the ladder
+    auto vm_wait = [&](int n) {
+#define B2B_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break
+        switch (n) {
+            B2B_VM(2); B2B_VM(3); B2B_VM(4); B2B_VM(5); B2B_VM(6); B2B_VM(7); B2B_VM(8); B2B_VM(9); B2B_VM(10); B2B_VM(11);
+            B2B_VM(12); B2B_VM(13); B2B_VM(14); B2B_VM(15); B2B_VM(16);
+            default:
+                if (n > 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#undef B2B_VM
+    };
+    // Before the barrier of step j: stage j+1 must have landed.  Issue order behind its DMAs (step j-2): the epilogue of step j-2,
+    // stage j+2's DMAs (step j-1), the epilogue of step j-1.  `cs` already names step j+1 here.
+    auto wait_next_stage = [&]() {
+        if (remaining > 1) {
+            int i2 = cs + 1;                               // stage j+2's index in its tile
+            if (i2 >= T) i2 -= T;
+            vm_wait(epi_prev2 + (i2 < S2 ? CNT2 : CNT3) + epi_prev);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+
+    f32x4 a0, b0, a1, b1;
+    issue(0);
+    issue(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT2) : "memory");        // stage 0 landed (stage 1's DMAs may be in flight)
+    B2B_BARRIER();
+    B2B_STAMP_AT(1);
+    issue(2);
+    B2B_RD(a0, SN_RA0, a_frag[0], 0);
+    B2B_RD(b0, SN_RB0, b_frag[0], 0);
+
+    // ---- phase 0: one K-step of conv2 on ring slot SLOT (transposed accumulators)
+    auto step2 = [&](auto slot_c) -> bool {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int OFF = SLOT * STAGE_BYTES, OFF_NEXT = ((SLOT + 1) % 3) * STAGE_BYTES;
+        B2B_WAIT0();
+        B2B_MFT(a0, b0, x);
+        B2B_RD(a1, SN_RA1, a_frag[1], OFF); B2B_RD(b1, SN_RB1, b_frag[1], OFF);
+        B2B_MFT(a0, b0, y);
+        B2B_MFT(a0, b0, z);
+        B2B_MFT(a0, b0, w);
+        B2B_WAIT1();
+        B2B_MFT(a1, b1, x);
+        B2B_RD(a0, SN_RA0, a_frag[2], OFF); B2B_RD(b0, SN_RB0, b_frag[2], OFF);
+        B2B_MFT(a1, b1, y);
+        B2B_MFT(a1, b1, z);
+        B2B_MFT(a1, b1, w);
+        B2B_WAIT0();
+        B2B_MFT(a0, b0, x);
+        B2B_RD(a1, SN_RA1, a_frag[3], OFF); B2B_RD(b1, SN_RB1, b_frag[3], OFF);
+        B2B_MFT(a0, b0, y);
+        B2B_MFT(a0, b0, z);
+        B2B_MFT(a0, b0, w);
+        B2B_WAIT1();                                       // every fragment of this stage is in registers
+        B2B_MFT(a1, b1, x);
+        --remaining;
+        ++cs;
+        const bool to_conv3 = cs == S2;                    // (remaining > 0 here: conv3 steps of this tile follow)
+        wait_next_stage();
+        B2B_BARRIER();                                     // publishes stage j+1, retires slot SLOT
+        B2B_RD(b0, SN_RB0, b_frag[0], OFF_NEXT);
+        if (!to_conv3) B2B_RD(a0, SN_RA0, a_frag[0], OFF_NEXT);
+        issue_part(SLOT, 0); __builtin_amdgcn_sched_barrier(0);           // stage j+3 into the slot just retired
+        B2B_MFT(a1, b1, y);
+        issue_part(SLOT, 1); __builtin_amdgcn_sched_barrier(0);
+        B2B_MFT(a1, b1, z);
+        issue_part(SLOT, 2); __builtin_amdgcn_sched_barrier(0);
+        B2B_MFT(a1, b1, w);
+        issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0);
+        epi_prev2 = epi_prev;
+        epi_prev = 0;
+        if (to_conv3) {
+            B2B_WAIT0();                                   // conv3's first B fragment: landed before the code below
+            B2B_STAMP_AT(2);
+            // park: relu(bn2(acc^T)) as NWN A stages.  Lane (m, h), quad q -> row wm*32 + m, chunk 2q + h of K-step wn.
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(acc[4 * qq + e], sc[qq][e], sh[qq][e]), 0.f);
+                asm volatile("ds_write_b128 %0, %1" ::"v"(park_wr[qq]), "v"(v) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            B2B_BARRIER();                                 // the whole tile is parked
+            B2B_RD(a0, SN_RA0, p_frag[0], 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+        return true;
+    };
+
+    // ---- phase 1: one K-step of conv3 (A from the park, B from ring slot SLOT)
+    auto step3 = [&](auto slot_c) -> bool {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int OFF = SLOT * STAGE_BYTES, OFF_NEXT = ((SLOT + 1) % 3) * STAGE_BYTES;
+        const int j3 = cs - S2;                            // conv3 step index: chunk j3 / NWN, K-step j3 % NWN
+        const unsigned pa = (unsigned)((j3 % NWN) * A_BYTES);
+        B2B_WAIT0();
+        B2B_MF(a0, b0, x);
+        { const unsigned ad = p_frag[1] + pa; B2B_RD(a1, SN_RA1, ad, 0); } B2B_RD(b1, SN_RB1, b_frag[1], OFF);
+        B2B_MF(a0, b0, y);
+        B2B_MF(a0, b0, z);
+        B2B_MF(a0, b0, w);
+        B2B_WAIT1();
+        B2B_MF(a1, b1, x);
+        { const unsigned ad = p_frag[2] + pa; B2B_RD(a0, SN_RA0, ad, 0); } B2B_RD(b0, SN_RB0, b_frag[2], OFF);
+        B2B_MF(a1, b1, y);
+        B2B_MF(a1, b1, z);
+        B2B_MF(a1, b1, w);
+        B2B_WAIT0();
+        B2B_MF(a0, b0, x);
+        { const unsigned ad = p_frag[3] + pa; B2B_RD(a1, SN_RA1, ad, 0); } B2B_RD(b1, SN_RB1, b_frag[3], OFF);
+        B2B_MF(a0, b0, y);
+        B2B_MF(a0, b0, z);
+        B2B_MF(a0, b0, w);
+        B2B_WAIT1();
+        B2B_MF(a1, b1, x);
+        --remaining;
+        ++cs;
+        const bool chunk_done = ((j3 + 1) % NWN) == 0;
+        const bool tile_done = cs == T;
+        const int n0 = (j3 / NWN) * BN2;                   // the chunk's first output channel
+        const int m0 = ct * BM;
+        const bool more = remaining > 0;
+        if (tile_done) { cs = 0; ct += t_stride; }
+        if (more) {
+            wait_next_stage();
+            B2B_BARRIER();
+            B2B_RD(b0, SN_RB0, b_frag[0], OFF_NEXT);
+            if (tile_done) {
+                B2B_RD(a0, SN_RA0, a_frag[0], OFF_NEXT);   // the next tile's first conv2 stage
+            } else {
+                const unsigned ad = p_frag[0] + (chunk_done ? 0u : pa + (unsigned)A_BYTES);
+                B2B_RD(a0, SN_RA0, ad, 0);
+            }
+        }
+        issue_part(SLOT, 0); __builtin_amdgcn_sched_barrier(0);
+        B2B_MF(a1, b1, y);
+        issue_part(SLOT, 1); __builtin_amdgcn_sched_barrier(0);
+        B2B_MF(a1, b1, z);
+        issue_part(SLOT, 2); __builtin_amdgcn_sched_barrier(0);
+        B2B_MF(a1, b1, w);
+        issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0);
+        epi_prev2 = epi_prev;
+        epi_prev = 0;
+        if (chunk_done) {
+            if (more) B2B_WAIT0();                         // the next step's first fragments: landed before the epilogue code
+            B2B_STAMP_AT(3);
+            b2b_chunk_epilogue(acc, q3, m0 + wm * 32, n0 + wn * 32, lane, scr_base);
+            if (m0 + BM <= q3.M) epi_prev = P.epi_vmem;    // (a ragged tile may skip stores: counted as zero -> the next wait is strict)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+        return more;
+    };
+
+    using s0 = std::integral_constant<int, 0>;
+    using s1 = std::integral_constant<int, 1>;
+    using s2 = std::integral_constant<int, 2>;
+    while (true) {
+        if (!(cs < S2 ? step2(s0{}) : step3(s0{}))) break;
+        if (!(cs < S2 ? step2(s1{}) : step3(s1{}))) break;
+        if (!(cs < S2 ? step2(s2{}) : step3(s2{}))) break;
+    }
+    B2B_STAMP_AT(4);
+#undef B2B_RD
+#undef B2B_WAIT0
+#undef B2B_WAIT1
+#undef B2B_MF
+#undef B2B_MFT
+#undef B2B_BARRIER
+}

@@ -26,7 +26,7 @@
 extern "C" int stabnet_black_accumulate(const float* black, int* all_black, long n, void* stream);
 
 enum { PK_CONV_W = 0, PK_BIAS = 1, PK_GAMMA = 2, PK_BETA = 3, PK_MEAN = 4, PK_VAR = 5, PK_FC_W = 6, PK_FC_B = 7 };
-enum { S_PAD = 0, S_CONV = 1, S_POOL = 2, S_GAP = 3, S_FC = 4 };
+enum { S_PAD = 0, S_CONV = 1, S_POOL = 2, S_GAP = 3, S_FC = 4, S_CONV_B2B = 5 /* conv2 -> conv3 of a unit as one launch (inference) */ };
 static int fc_launches(int M) { int n = 0, m0 = 0; for (; M - m0 > 8; m0 += 16) ++n; return n + (m0 < M ? 1 : 0); }   // launch_fc's passes
 static const long EXT_IN = -2, EXT_OUT = -3, NONE = -1;
 
@@ -48,6 +48,11 @@ struct Step {
     int inf_preactivated;                        // inference only: the input tensor already holds relu(bn(.)) -> no prologue
     long fvec_off;                               // inference only: per-channel (bias, scale, shift, floor) vectors of a merged
                                                  // shortcut|conv1 launch, offset inside the merge region of `fold` (-1: none)
+    // S_CONV_B2B (inference plans): `conv` is the unit's 3x3 conv2 (in_off, w_off; its consumer BN bn2 = mid_obn_off), `conv_b` its
+    // 1x1 conv3 (w3_off, b_off, res_off, out_off, obn_off = the NEXT unit's pre-activation, if fused); mid_out_off = conv2's own
+    // output tensor, written only when the step runs as two launches (bf16-operand mode)
+    ConvArgs conv_b;
+    long mid_obn_off, w3_off, mid_out_off;
     int N, H, W, C, Ho, Wo, k, stride, pt, pl;   // pool / pad / gap
     int M, K, Nout, relu;                        // fc
     size_t splitk_bytes;
@@ -279,7 +284,7 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             // is a conv of the pre-activation), so its producer -- the max-pool or the previous block's last conv3 -- applies
             // this unit's preact BN + ReLU itself and both convs of the unit run prologue-free on the ring kernel.
             const bool pre_act = !keep_all && want_ring && cin != b.depth && !net->steps.empty() &&
-                                 (net->steps.back().kind == S_POOL || net->steps.back().kind == S_CONV) &&
+                                 (net->steps.back().kind == S_POOL || net->steps.back().kind == S_CONV || net->steps.back().kind == S_CONV_B2B) &&
                                  net->steps.back().out_off == cur.off && net->steps.back().obn_off < 0;
             if (pre_act) net->steps.back().obn_off = bn_pre;
             auto mark_preactivated = [&](Step& st_) {
@@ -367,6 +372,24 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
                     net->splitk_bytes = std::max(net->splitk_bytes, c3.splitk_bytes);
                 }
                 ui.w3 = w; ui.b3 = bb;
+            }
+            // Inference plan, block 1 / block 2 units with enough 64-pixel tiles to fill the chip: conv2 and conv3 as ONE launch
+            // (conv_b2b_kernel.h): the activated conv2 tile stays in LDS, the low-K conv3 launch and the round trip of its input go.
+            if (!keep_all && i_conv2 + 2 == net->steps.size()) {
+                static const int min_tiles = []() { const char* v = getenv("STABNET_CONV_B2B_MIN_TILES"); return v ? atoi(v) : 200; }();
+                const Step c2 = net->steps[i_conv2], c3 = net->steps[i_conv2 + 1];
+                if (conv_b2b_supported(c2.conv, c3.conv) && (c3.conv.M + 63) / 64 >= min_tiles) {
+                    Step f = c2;
+                    f.kind = S_CONV_B2B;
+                    f.conv_b = c3.conv;
+                    f.mid_obn_off = c2.obn_off; f.mid_out_off = c2.out_off;
+                    f.w3_off = c3.w_off; f.b_off = c3.b_off; f.res_off = c3.res_off; f.out_off = c3.out_off;
+                    f.obn_off = NONE;                        // conv3's consumer BN: set by the next unit if it is a projection unit
+                    f.splitk_bytes = std::max(c2.splitk_bytes, c3.splitk_bytes);
+                    net->steps.pop_back();
+                    net->steps.pop_back();
+                    net->steps.push_back(f);
+                }
             }
             ui.sc = sc; ui.r1 = r1; ui.r2 = r2; ui.out = nxt; ui.proj = own_sc; ui.bn1 = bn1; ui.bn2 = bn2;
             net->units.push_back(ui);
@@ -485,7 +508,7 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
         int rc = STABNET_OK;
         if (s.kind == S_PAD && skip_pad) continue;
         if (s.kind == S_FC && fused_head && (s.in_off == net->t_gap.off || s.out_off == EXT_OUT)) continue;   // fc_1 rides with the GAP, the output layer with the mesh
-        const bool rec = (s.kind != S_CONV) && prof != nullptr && prof->begin(st);
+        const bool rec = (s.kind != S_CONV && s.kind != S_CONV_B2B) && prof != nullptr && prof->begin(st);
         switch (s.kind) {
             case S_PAD:
                 if (net->stem_rowrun) rc = launch_embed_border(x, s.N, s.H, s.W, s.C, 3, ws + s.out_off, st);   // (+ the slack row)
@@ -513,6 +536,23 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
                 }
                 a.partial = splitk;
                 rc = conv_launch(a, st, prof, net->bf16_operands);
+                break;
+            }
+            case S_CONV_B2B: {
+                ConvArgs a = s.conv, b = s.conv_b;
+                a.x = ws + s.in_off; a.w = params + s.w_off; a.y = ws + s.mid_out_off;
+                a.out_scale = scale + s.mid_obn_off; a.out_shift = shift + s.mid_obn_off; a.relu_out = 1;
+                b.x = ws + s.mid_out_off; b.w = params + s.w3_off; b.y = ws + s.out_off;
+                b.bias = s.b_off >= 0 ? params + s.b_off : nullptr;
+                b.residual = s.res_off >= 0 ? ws + s.res_off : nullptr;
+                if (s.obn_off >= 0) { b.out_scale = scale + s.obn_off; b.out_shift = shift + s.obn_off; b.relu_out = 1; }
+                a.partial = b.partial = splitk;
+                if (net->bf16_operands) {                  // the fused kernel is fp32 only: the secondary mode runs the two launches
+                    rc = conv_launch(a, st, prof, 1);
+                    if (!rc) rc = conv_launch(b, st, prof, 1);
+                } else {
+                    rc = conv_b2b_launch(a, b, st, prof);
+                }
                 break;
             }
             case S_POOL:
@@ -649,6 +689,8 @@ const char* stabnet_prof_kind_name(int kind) {
     if (kind == PK_KERNEL_CONV_RING + 3) return "conv_ring_f32_kernel<0, 1, 1, 0>";
     if (kind == PK_KERNEL_CONV_RING + 4) return "conv_ring_f32_kernel<1, 1, 1, 0>";
     if (kind == PK_KERNEL_CONV_RING + 5) return "conv_ring_f32_kernel<2, 1, 1, 0>";
+    if (kind == PK_KERNEL_CONV_B2B) return "conv_b2b_f32_kernel<2>";
+    if (kind == PK_KERNEL_CONV_B2B + 1) return "conv_b2b_f32_kernel<4>";
     if (kind >= PK_KERNEL_CONV_BASE && kind < PK_KERNEL_CONV_BASE + 72) {
         // names as rocprofv3 prints the template instantiation: <BM, BN, BK, WM, WN, MODE, NBUF, BF16>
         // (kind = base + MODE*6 + tile*2 + (BK==32) + 18 if NBUF == 1 + 36 if BF16, conv.hip)
@@ -720,7 +762,10 @@ int stabnet_net_num_launches(const void* netp) {
     if (!net) return -1;
     int n = 0;
     // (shortened head: GAP partials + fc_1 = 2 launches, fc_2, fc_3, output layer [+ mesh] = 3; else 2 + 4 x fc_launches)
-    for (const Step& s : net->steps) n += (s.kind == S_CONV) ? 1 + conv_reduce_launches(s.conv) : (s.kind == S_FC ? fc_launches(s.M) : (s.kind == S_GAP ? 2 : 1));
+    for (const Step& s : net->steps) {
+        if (s.kind == S_CONV_B2B && net->bf16_operands) n += 2 + conv_reduce_launches(s.conv) + conv_reduce_launches(s.conv_b);   // runs as two launches there
+        else n += (s.kind == S_CONV) ? 1 + conv_reduce_launches(s.conv) : (s.kind == S_FC ? fc_launches(s.M) : (s.kind == S_GAP ? 2 : 1));
+    }
     if (head_fused_supported(net->N, net->t_last.C, net->fc_dims)) n -= 1 /* gap_finalize */ + (fc_launches(net->N) - 1) * 2;
     return n;
 }

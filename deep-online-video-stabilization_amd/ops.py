@@ -42,6 +42,34 @@ def conv2d(x, w_ohwi, bias=None, in_scale=None, in_shift=None, residual=None, re
     return y
 
 
+def conv3x3_conv1x1(x, w2_ohwi, mid_scale, mid_shift, w3_ohwi, bias3=None, residual=None, res_stride=1, stride=1, relu_out=False,
+                    out_scale=None, out_shift=None, x_ch0=0, res_ch0=0):
+    """The tail of a bottleneck unit as one launch (stabnet_conv3x3_conv1x1_fwd): conv2 3x3 (pad 1, `stride`) -> folded BN + ReLU
+    -> conv3 1x1 with conv2d's epilogue.  x [N,H,W,Cx]: the conv reads channels x_ch0 .. x_ch0 + C of every pixel (Cx > C: the
+    inference plan's merged shortcut|conv1 buffer); residual [N,rH,rW,Cr]: channels res_ch0 .. res_ch0 + Cout likewise."""
+    x = dev_f32(x, "x")
+    w2 = dev_f32(w2_ohwi, "w2")
+    w3 = dev_f32(w3_ohwi, "w3")
+    N, H, W, Cx = x.shape
+    C = w2.shape[0]
+    Cout = w3.shape[0]
+    assert tuple(w2.shape) == (C, 3, 3, C) and tuple(w3.shape[1:]) == (1, 1, C) and x_ch0 + C <= Cx
+    Ho = (H + 2 - 3) // stride + 1
+    Wo = (W + 2 - 3) // stride + 1
+    y = empty((N, Ho, Wo, Cout), x)
+    rH = rW = res_ld = 0
+    rp = 0
+    if residual is not None:
+        residual = dev_f32(residual, "residual")
+        rH, rW, res_ld = residual.shape[1], residual.shape[2], residual.shape[3]
+        assert res_ch0 + Cout <= res_ld
+        rp = residual.data_ptr() + 4 * res_ch0
+    _lib.call("stabnet_conv3x3_conv1x1_fwd", x.data_ptr() + 4 * x_ch0, Cx, ptr(w2), ptr(mid_scale), ptr(mid_shift), ptr(w3),
+              ptr(bias3), rp, rH, rW, res_stride, res_ld, ptr(out_scale), ptr(out_shift), ptr(y), N, H, W, C, Cout, stride,
+              int(relu_out), stream_ptr(x.device), device=x.device)
+    return y
+
+
 def conv2d_wgrad(x, dy, w_shape, in_scale=None, in_shift=None, stride=1, pad=0, dw=None):
     """dW (OHWI) += d conv / d W; returns dw (zero-initialised when not given)."""
     x = dev_f32(x, "x")

@@ -85,6 +85,17 @@ int stabnet_conv2d_fwd_ex(const float* x, const float* w_ohwi, const float* bias
                           const float* out_scale, const float* out_shift, float* y, int N, int H, int W, int Cin,
                           int Cout, int KH, int KW, int stride, int pad, int relu_out, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* The tail of a slim bottleneck_v2 unit as ONE launch (resnet_v2 `bottleneck`, called at s_net_bundle_nobm.py:252-253; what the
+ * inference plan runs for the block-1 / block-2 units of a frame): conv2 (3x3, pad 1, stride 1 | 2, C -> C channels, C = 64 | 128,
+ * no bias) -> folded batch_norm (mid_scale, mid_shift) + ReLU -> conv3 (1x1, C -> Cout, Cout % C == 0) with conv2d_fwd_ex's
+ * epilogue: y = act((conv3 + bias3 + residual) * out_scale + out_shift).  The C-channel intermediate never reaches memory (a
+ * workgroup keeps its activated 64-pixel tile in LDS and feeds the 1x1 GEMM from there).  x [N,H,W,C] with x_ld floats between
+ * pixels (0 = C); residual read at (oy*res_stride, ox*res_stride) with res_ld floats between pixels (0 = Cout); y [N,Ho,Wo,Cout].
+ * No workspace.  STABNET_ERR_BAD_ARG for other geometries (use two stabnet_conv2d_fwd_ex calls). */
+int stabnet_conv3x3_conv1x1_fwd(const float* x, int x_ld, const float* w2_ohwi, const float* mid_scale, const float* mid_shift,
+                                const float* w3_ohwi, const float* bias3, const float* residual, int res_H, int res_W,
+                                int res_stride, int res_ld, const float* out_scale, const float* out_shift, float* y, int N, int H,
+                                int W, int C, int Cout, int stride, int relu_out, void* stream);
 
 /* ---- the regressor as one plan --------------------------------------------------------------------------
  * get_resnet(x_tensor, reuse, is_training=False, x_batch_size) -> theta       s_net_bundle_nobm.py:250-264

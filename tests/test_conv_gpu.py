@@ -209,3 +209,82 @@ def test_prologue_vectors_in_any_address_order(cuda, split):
     for g in got.values():
         assert np.isfinite(g).all() and np.abs(g - want).max() <= 2e-5 * scale
     assert np.abs(got["shift_above"] - got["shift_below"]).max() <= 1e-5 * scale    # two kernels, float32 summation order only
+
+
+# conv2 (3x3) -> bn2 + ReLU -> conv3 (1x1) as ONE launch (conv_b2b_kernel.h; the block-1 / block-2 units of an inference frame).
+# N,H,W,C,Cout,stride, bias, residual (0 none, 1 same size, 2 strided identity shortcut), relu, x_ch0 / extra channels of the input buffer
+B2B_CASES = [
+    (1, 9, 16, 64, 256, 1, True, 1, False, 0, 0),         # 3 ragged-free tiles... 144 px: 2 full tiles + a ragged one (64-row tiles)
+    (1, 17, 23, 64, 256, 1, True, 1, True, 0, 0),         # ragged last tile, image borders everywhere
+    (2, 36, 64, 64, 256, 1, True, 1, False, 0, 0),        # 72 tiles, two images (taps must not cross the image boundary)
+    (1, 37, 63, 64, 256, 2, True, 2, False, 0, 0),        # stride 2, odd sizes, strided identity shortcut (block-1 unit 3)
+    (1, 36, 64, 64, 256, 1, True, 1, False, 256, 0),      # input = channels 256..319 of a 320-channel buffer (merged shortcut|conv1)
+    (1, 36, 64, 64, 256, 1, True, 1, False, 256, 1),      # ... and the residual = channels 0..255 of the SAME buffer (projection unit)
+    (1, 36, 64, 64, 128, 1, False, 0, True, 0, 0),        # Cout = 2 chunks, no bias, no residual
+    (1, 180, 320, 64, 256, 1, True, 1, False, 0, 0),      # the 720p block-1 shape: 900 tiles > 512 resident workgroups
+    (1, 9, 16, 128, 512, 1, True, 1, False, 0, 0),        # d_b = 128: the 8-wave form
+    (1, 23, 17, 128, 512, 1, True, 1, True, 0, 0),        # ragged
+    (1, 37, 63, 128, 512, 2, True, 2, False, 0, 0),       # stride 2 (block-2 unit 4)
+    (1, 36, 64, 128, 512, 1, True, 1, False, 512, 1),     # merged buffer, 640 channels
+    (1, 90, 160, 128, 512, 1, True, 1, False, 0, 0),      # the 720p block-2 shape: 225 tiles, one per CU
+    (2, 90, 160, 128, 512, 1, True, 1, False, 0, 0),      # 450 tiles: two per workgroup, the ring running across the tile boundary
+]
+
+
+@pytest.mark.parametrize("out_bn", [False, True])
+@pytest.mark.parametrize("N,H,W,C,Cout,stride,bias,res,relu,x_ch0,res_in_x", B2B_CASES)
+def test_conv3x3_conv1x1_one_launch(cuda, N, H, W, C, Cout, stride, bias, res, relu, x_ch0, res_in_x, out_bn):
+    """vs the oracle's two convolutions, and vs the library's own two launches (same K order, no split: bit-identical)."""
+    from stabnet_amd import _lib, ops
+    rng = np.random.default_rng(C * 11 + Cout + H + stride)
+    Cx = x_ch0 + C
+    xfull = rng.standard_normal((N, H, W, Cx)).astype(np.float32)
+    x = np.ascontiguousarray(xfull[..., x_ch0:])
+    w2 = (rng.standard_normal((3, 3, C, C)) * np.sqrt(2.0 / (9 * C))).astype(np.float32)
+    w3 = (rng.standard_normal((1, 1, C, Cout)) * np.sqrt(2.0 / C)).astype(np.float32)
+    b3 = rng.standard_normal(Cout).astype(np.float32) if bias else None
+    msc = rng.uniform(0.5, 1.5, C).astype(np.float32)
+    msh = (rng.standard_normal(C) * 0.3).astype(np.float32)
+    mid = O.conv2d(x, w2, stride, ((1, 1), (1, 1)), None)
+    mid = np.maximum(mid * msc + msh, 0).astype(np.float32)
+    want = O.conv2d(mid, w3, 1, ((0, 0), (0, 0)), b3)
+    Ho, Wo = want.shape[1:3]
+    r = None
+    if res_in_x:
+        assert res == 1 and stride == 1 and x_ch0 >= Cout
+        r = xfull                                                        # channels 0 .. Cout of the input buffer
+        want = want + xfull[..., :Cout]
+    elif res == 1:
+        r = rng.standard_normal((N, Ho, Wo, Cout)).astype(np.float32)
+        want = want + r
+    elif res == 2:
+        r = rng.standard_normal((N, 2 * Ho - 1, 2 * Wo, Cout)).astype(np.float32)
+        want = want + r[:, ::2, ::2, :]
+    osc = osh = None
+    if out_bn:
+        osc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+        osh = (rng.standard_normal(Cout) * 0.3).astype(np.float32)
+        want = (want * osc + osh).astype(np.float32)
+    if relu:
+        want = np.maximum(want, 0)
+    t = lambda v: None if v is None else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(cuda)
+    xg = t(xfull)
+    rg = xg if res_in_x else t(r)
+    W2, W3 = t(ops.pack_conv_weight(w2)), t(ops.pack_conv_weight(w3))
+    got = ops.conv3x3_conv1x1(xg, W2, t(msc), t(msh), W3, t(b3), rg, 2 if res == 2 else 1, stride, relu, t(osc), t(osh), x_ch0=x_ch0)
+    got_b = ops.conv3x3_conv1x1(xg, W2, t(msc), t(msh), W3, t(b3), rg, 2 if res == 2 else 1, stride, relu, t(osc), t(osh), x_ch0=x_ch0)
+    got, got_b = got.cpu().numpy(), got_b.cpu().numpy()
+    assert got.shape == want.shape and np.isfinite(got).all()
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= (6e-5 if out_bn else 3e-5) * scale, np.abs(got - want).max() / scale
+    assert np.array_equal(got, got_b)
+    # the two-launch form of the same tail through the public conv operator, K unsplit: the same products in the same order
+    L = _lib.lib()
+    try:
+        L.stabnet_conv_tuning_override(2, 1)
+        mid_g = ops.conv2d(t(x), W2, None, None, None, None, 1, stride, 1, True, out_scale=t(msc), out_shift=t(msh))
+        rr = t(np.ascontiguousarray(xfull[..., :Cout])) if res_in_x else t(r)
+        two = ops.conv2d(mid_g, W3, t(b3), None, None, rr, 2 if res == 2 else 1, 1, 0, relu, out_scale=t(osc), out_shift=t(osh))
+    finally:
+        L.stabnet_conv_tuning_override(-1, -1)
+    assert np.array_equal(got, two.cpu().numpy())
