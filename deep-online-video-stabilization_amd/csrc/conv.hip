@@ -473,6 +473,9 @@ int conv_launch_pair(const ConvArgs& a, const ConvPair& pr, hipStream_t st, Prof
 
 // ---- conv2 (3x3) -> conv3 (1x1) back to back (conv_b2b_kernel.h) ------------------------------------------
 bool conv_b2b_supported(const ConvArgs& c2, const ConvArgs& c3) {
+    // A LAUNCH strategy the inference plan does not choose by default (STABNET_CONV_B2B_PLAN=1 turns it on, net.hip): measured
+    // in the 720p frame it loses to the two launches at every unit it applies to.  The operator
+    // itself (stabnet_conv3x3_conv1x1_fwd) is always available.
     static const int on = env_int("STABNET_CONV_B2B", 1);
     if (g_ring < 0) g_ring = env_int("STABNET_CONV_RING", 1);
     const bool g2 = c2.KH == 3 && c2.KW == 3 && c2.pad == 1 && c2.up == 1 && !c2.rowrun && (c2.stride == 1 || c2.stride == 2) &&
@@ -499,7 +502,6 @@ int conv_b2b_launch(const ConvArgs& c2, const ConvArgs& c3, hipStream_t st, Prof
     P.c3 = c3;
     P.c3.splitk = 1;                                                  // the accumulators handed to the epilogue are the full sum
     P.c3.steps_per_split = conv_total_steps(c3);
-    P.epi_vmem = 4 + (c3.residual ? 4 : 0) + (c3.bias ? 1 : 0) + (c3.out_scale ? 2 : 0) + ((c3.out_scale && c3.out_floor) ? 1 : 0);
     const int tiles_m = cdiv(c2.M, 64);
     const bool rec = prof != nullptr && prof->begin(st);
     if (c2.Cout == 64) {

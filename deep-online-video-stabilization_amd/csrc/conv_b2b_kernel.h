@@ -15,15 +15,15 @@
 //   phase 1 (S3 = (Cout3 / 32 NWN) * NWN steps): conv3 walks its N in chunks of 32 NWN channels, NWN K-steps each.  A fragments
 //            come from the park, B stages (W3 rows of the chunk, [32 NWN][32]) from the SAME ring -- they do not depend on phase
 //            0, so the producer side streams them three stages ahead like any other stage, across the phase and tile boundaries.
-//            Each chunk ends with the ring kernel's full epilogue (bias + residual + the next unit's folded BN + ReLU / floor,
-//            16 B per lane through a wave-private LDS transpose).
+//            conv3 runs with swapped operands too (one step body for both phases); each chunk ends with the ring kernel's full
+//            epilogue (bias + residual + the next unit's folded BN + ReLU / floor, 16 B per lane through a wave-private LDS
+//            transpose -- from the transposed layout that is four ds_write_b128 instead of sixteen ds_write_b32).
 //
 // Differences from conv_ring_kernel.h that matter for speed:
 //   * the epilogue scratch is NOT a ring slot (dedicated 4 KB per wave): a chunk's end neither stalls the producer nor needs the
 //     extra barrier, which matters when a "tile" is only NWN = 2 / 4 steps long;
-//   * waits are counted past the epilogue: `s_waitcnt vmcnt(N)` with N = DMAs of the youngest stage + the VMEM operations of the
-//     chunk epilogue issued behind it (P.epi_vmem, interior tiles only), so the stores of chunk c drain under the MFMAs of
-//     chunk c + 1 instead of being waited for at its first barrier.
+//   * a chunk's residual rows and per-channel vectors are fetched into (pinned) registers at the chunk's FIRST step by inline-asm
+//     loads: the epilogue itself has no load -> use latency (1.2 of the 1.5 us it took with the loads inside).
 //   NWN = 2: d_b = 64 (block 1), 4 waves, 80 KB of LDS (ring 48 + park 16 + scratch 16): two workgroups per CU.
 //   NWN = 4: d_b = 128 (block 2), 8 waves (2 x 4 of 32 x 32), 136 KB (72 + 32 + 32): one workgroup per CU.
 #pragma once
@@ -34,59 +34,35 @@ struct B2bArgs {
                      //   x / x_ld / w / geometry as for conv_ring_f32_kernel<1>; out_scale / out_shift = folded bn2 (ReLU implied); y unused
     ConvArgs c3;     // the 1x1 convolution of the parked tile (Cin == c2.Cout, M == c2.M): w, bias, residual (+ res_*), out_scale /
                      //   out_shift / out_floor / relu_out, y; planned by conv_plan() (M, div_*, res_ld), splitk == 1
-    int epi_vmem;    // VMEM operations one conv3 chunk epilogue issues per wave on an INTERIOR tile (b2b_chunk_epilogue: 4 stores +
-                     //   4 residual loads + bias + 2 for out_scale / out_shift + 1 for out_floor); must not exceed the real count
 };
 
-#ifndef B2B_STAMP
-#define B2B_STAMP 0            // probe-only: per-workgroup s_memrealtime stamps (tools/b2b_probe.hip)
-#endif
-#if B2B_STAMP
-__device__ unsigned long long g_b2b_stamps[2048 * 8];
-#define B2B_STAMP_AT(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_b2b_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define B2B_STAMP_AT(i) do { } while (0)
-#endif
-
+#ifndef B2B_ABLATE
+#define B2B_ABLATE 0           // probe-only bit mask (tools/b2b_probe.hip): 1 chunk epilogue without its global loads / stores, 2 no chunk
+#endif                         //   epilogue at all, 4 no park, 8 no MFMA
 // conv3's chunk epilogue: conv_epilogue<1, 1> (conv_kernel.h) -- same arithmetic, same order: + bias, + residual, * out_scale +
-// out_shift, floor / ReLU -- restated so that the number of vector-memory operations a wave issues is FIXED by the launch's flags
-// (the kernel counts them in its `s_waitcnt vmcnt`, see wait_next_stage): every per-channel vector is one 16-byte load of an
-// ext_vector (HIP's float4 struct is split by the compiler into four branchy 4-byte loads when the load is conditional).
-// Vector-memory operations of an interior tile: 4 stores + (residual: 4) + (bias: 1) + (out_scale, out_shift: 2) + (floor: 1).
-__device__ __forceinline__ void b2b_chunk_epilogue(const f32x16& a, const ConvArgs& p, int mw0, int nw0, int lane, unsigned scratch) {
+// out_shift, floor / ReLU -- restated for TRANSPOSED accumulators (conv3 runs with swapped MFMA operands like conv2, so that one
+// step body serves both phases): lane (m = lane & 31, h = lane >> 5) holds, in registers 4q .. 4q+3, channels 8q + 4h .. + 3 of
+// pixel row m.  Four ds_write_b128 put them into the wave's [32 pixels][32 channels] scratch (16-byte chunk index XOR (m & 7):
+// conflict-free for the writes and for the row-major ds_read_b128 that follow), then every lane owns FOUR CONSECUTIVE CHANNELS of
+// four pixels as in conv_epilogue: 16-byte stores, 128 B per 8 lanes.  The residual rows and the per-channel vectors are NOT
+// loaded here: the kernel fetched them into registers a chunk earlier (inline-asm loads it waits for with a counted vmcnt), so
+// the epilogue has no memory latency of its own -- measured, the load -> use wait was 1.2 of the 1.5 us a chunk epilogue took.
+// Vector-memory operations issued here: the 4 stores of an interior tile (a ragged tile may skip some: the caller counts 0).
+struct B2bEpiOperands { f32x4 rv[4], bv, os, ob, fl; };
+// part 1: transposition + arithmetic -> out[q] = the four channels n .. n+3 of pixel row rrow + 8q (no vector-memory operation)
+__device__ __forceinline__ void b2b_chunk_compute(const f32x16& a, const ConvArgs& p, int lane, unsigned scratch, const B2bEpiOperands& o,
+                                                  f32x4 (&out)[4]) {
     const bool has_res = p.residual != nullptr, has_obn = p.out_scale != nullptr, has_bias = p.bias != nullptr;
     const bool has_floor = has_obn && p.out_floor != nullptr, relu = p.relu_out != 0;
-    const bool res_plain = p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo;
-    const unsigned wr = scratch + (unsigned)(((4 * (lane >> 5)) * 32 + (lane & 31)) * 4);   // C/D role
-    const int rrow = lane >> 3, rc4 = (lane & 7) * 4;                                        // row-major role: rows rrow + 8q
-    const unsigned rd = scratch + (unsigned)((rrow * 32 + rc4) * 4);
-    const int n = nw0 + rc4;                                                                 // (< Cout: chunks are whole)
-    int mrow[4];
-    f32x4 rv[4];
+    const int tm = lane & 31, th = lane >> 5;                                                // transposed C/D role
+    const int rrow = lane >> 3, rc = lane & 7;                                               // row-major role: rows rrow + 8q, chunk rc
+    const unsigned rd = scratch + (unsigned)(rrow * 128 + ((rc ^ rrow) << 4));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        mrow[q] = mw0 + rrow + 8 * q;
-        if (has_res) {
-            const int m = min(mrow[q], p.M - 1);
-            unsigned roff;
-            if (res_plain) {
-                roff = (unsigned)(m * p.res_ld);
-            } else {
-                const int img = sn_fastdiv(m, p.div_hw_mul, p.div_hw_shift);
-                const int rr = m - img * (p.Ho * p.Wo);
-                const int oy = sn_fastdiv(rr, p.div_w_mul, p.div_w_shift), ox = rr - oy * p.Wo;
-                roff = (unsigned)(((img * p.res_H + oy * p.res_stride) * p.res_W + ox * p.res_stride) * p.res_ld);
-            }
-            rv[q] = *reinterpret_cast<const f32x4*>(p.residual + (roff + (unsigned)n));
-        }
+        const f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+        const unsigned wr = scratch + (unsigned)(tm * 128 + (((2 * q + th) ^ (tm & 7)) << 4));
+        asm volatile("ds_write_b128 %0, %1" ::"v"(wr), "v"(v) : "memory");
     }
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 bv = zero4, os = zero4, ob = zero4, fl = zero4;
-    if (has_bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-    if (has_obn) { os = *reinterpret_cast<const f32x4*>(p.out_scale + n); ob = *reinterpret_cast<const f32x4*>(p.out_shift + n); }
-    if (has_floor) fl = *reinterpret_cast<const f32x4*>(p.out_floor + n);
-    SN_EPI_W(0); SN_EPI_W(1); SN_EPI_W(2); SN_EPI_W(3); SN_EPI_W(4); SN_EPI_W(5); SN_EPI_W(6); SN_EPI_W(7);
-    SN_EPI_W(8); SN_EPI_W(9); SN_EPI_W(10); SN_EPI_W(11); SN_EPI_W(12); SN_EPI_W(13); SN_EPI_W(14); SN_EPI_W(15);
     f32x4 t[4];
     SN_EPI_R(0, t[0]); SN_EPI_R(1, t[1]); SN_EPI_R(2, t[2]); SN_EPI_R(3, t[3]);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])::"memory");
@@ -95,14 +71,24 @@ __device__ __forceinline__ void b2b_chunk_epilogue(const f32x16& a, const ConvAr
         f32x4 v = t[q];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float x = v[e] + bv[e];
-            if (has_res) x += rv[q][e];
-            if (has_obn) x = __builtin_fmaf(x, os[e], ob[e]);
-            if (has_floor) x = fmaxf(x, fl[e]);
+            float x = v[e] + (has_bias ? o.bv[e] : 0.f);
+            if (has_res) x += o.rv[q][e];
+            if (has_obn) x = __builtin_fmaf(x, o.os[e], o.ob[e]);
+            if (has_floor) x = fmaxf(x, o.fl[e]);
             else if (relu) x = fmaxf(x, 0.f);
             v[e] = x;
         }
-        if (mrow[q] < p.M) *reinterpret_cast<f32x4*>(p.y + ((size_t)mrow[q] * p.Cout + n)) = v;
+        out[q] = v;
+    }
+}
+// part 2: the four 16-byte stores (128 B per 8 lanes)
+__device__ __forceinline__ void b2b_chunk_store(const f32x4 (&out)[4], const ConvArgs& p, int mw0, int nw0, int lane) {
+    const int rrow = lane >> 3, n = nw0 + (lane & 7) * 4;                                   // (n < Cout: chunks are whole)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int mrow = mw0 + rrow + 8 * q;
+        if (!(B2B_ABLATE & 1)) { if (mrow < p.M) *reinterpret_cast<f32x4*>(p.y + ((size_t)mrow * p.Cout + n)) = out[q]; }
+        else if (out[q][0] == 123.456f) p.y[0] = out[q][1];
     }
 }
 
@@ -117,14 +103,13 @@ __global__ __launch_bounds__(128 * NWN) void conv_b2b_f32_kernel(const B2bArgs P
     constexpr int PARK_BYTES = NWN * A_BYTES;              // the activated conv2 tile as NWN A stages
     constexpr int SCR_BYTES = NW * SN_EPI_WAVE_BYTES;
     constexpr int A_PER_WAVE = 8 / NW;                     // A DMA instructions (8 rows each) per wave and conv2 stage: 2 / 1
-    constexpr int CNT2 = A_PER_WAVE + 2, CNT3 = 2;         // DMAs per wave in a conv2 / conv3 stage
+    constexpr int CNT2 = A_PER_WAVE + 2;                   // DMAs per wave in a conv2 stage (a conv3 stage: 2)
     __shared__ __attribute__((aligned(16))) float lds[(3 * STAGE_BYTES + PARK_BYTES + SCR_BYTES) / 4];
 
     const ConvArgs& p = P.c2;
     const ConvArgs& q3 = P.c3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NWN, wn = wave % NWN;
-    B2B_STAMP_AT(0);
     const int tiles_m = (p.M + BM - 1) / BM;
     int t_first = blockIdx.x, t_stride = gridDim.x, t_end = tiles_m;
     if (p.xcd_swizzle && gridDim.x >= 8) {                 // workgroups of one XCD take one contiguous run of M tiles (conv_ring_kernel.h)
@@ -269,17 +254,15 @@ __global__ __launch_bounds__(128 * NWN) void conv_b2b_f32_kernel(const B2bArgs P
     // ---- consumer state
     int ct = t_first;                                      // tile being computed
     int cs = 0;                                            // its step index: [0, S2) conv2, [S2, T) conv3
-    int epi_prev = 0, epi_prev2 = 0;                       // VMEM operations of the epilogues issued at the end of the previous step / the one before
 
     // ---- fragment read addresses (LDS bytes): lane (i = lane & 31, h = lane >> 5) reads logical chunk 2kk + h of its row
-    unsigned a_frag[4], b_frag[4], p_frag[4], park_wr[4];
+    unsigned a_frag[4], b_frag[4], park_wr[4];
     {
         const int ra = wm * 32 + (lane & 31), rb = wn * 32 + (lane & 31), h = lane >> 5;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const unsigned rel = 4u * (unsigned)(ra * BK + (((2 * kk + h) ^ ((ra >> 1) & 7)) << 2));
             a_frag[kk] = lds_base + rel;
-            p_frag[kk] = park_base + rel;
             park_wr[kk] = park_base + (unsigned)(wn * A_BYTES) + rel;     // accumulator quad q = kk: K-step wn of the parked tile
             b_frag[kk] = lds_base + (unsigned)A_BYTES + 4u * (unsigned)(rb * BK + (((2 * kk + h) ^ ((rb >> 1) & 7)) << 2));
         }
@@ -293,35 +276,76 @@ __global__ __launch_bounds__(128 * NWN) void conv_b2b_f32_kernel(const B2bArgs P
 
     // Fragment reads / waits / MFMAs: the ring kernel's discipline (inline asm LDS reads on pinned registers, explicit lgkmcnt
     // waits tied to the fragment registers, every non-MFMA instruction right behind one MFMA).
+    // (SN_RA0 .. SN_RB1: the pinned fragment registers v[100:115], defined by conv_ring_kernel.h)
 #define B2B_RD(dst, reg, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=" reg(dst) : "v"(addr), "n"(off))
 #define B2B_WAIT0() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA0(a0), "+" SN_RB0(b0))
 #define B2B_WAIT1() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA1(a1), "+" SN_RB1(b1))
-#define B2B_MF(a, b, c)  do { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.c, b.c, acc, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define B2B_MFT(a, b, c) do { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.c, a.c, acc, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define B2B_MFT(a, b, c)                                                                                     \
+    do {                                                                                                     \
+        if (!(B2B_ABLATE & 8)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.c, a.c, acc, 0, 0, 0);           \
+        else acc[0] += a.c * b.c;                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
 #define B2B_BARRIER() do { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-    // (SN_RA0 .. SN_RB1: the pinned fragment registers v[100:115], defined by conv_ring_kernel.h)
-    // `s_waitcnt vmcnt` takes an immediate: any value <= n is correct (stricter), so n is rounded down to the ladder
-    auto vm_wait = [&](int n) {
-#define B2B_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break
-        switch (n) {
-            B2B_VM(2); B2B_VM(3); B2B_VM(4); B2B_VM(5); B2B_VM(6); B2B_VM(7); B2B_VM(8); B2B_VM(9); B2B_VM(10); B2B_VM(11);
-            B2B_VM(12); B2B_VM(13); B2B_VM(14); B2B_VM(15); B2B_VM(16);
-            default:
-                if (n > 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the epilogue operands fetched a chunk ahead: fixed registers, like the fragments (a copy between a load and its wait would
+    // copy stale contents; tools/check_pinned_regs.py looks for such copies in the ISA)
+#define B2B_RV0 "{v[132:135]}"
+#define B2B_RV1 "{v[136:139]}"
+#define B2B_RV2 "{v[140:143]}"
+#define B2B_RV3 "{v[144:147]}"
+#define B2B_RBV "{v[148:151]}"
+#define B2B_ROS "{v[152:155]}"
+#define B2B_ROB "{v[156:159]}"
+#define B2B_RFL "{v[160:163]}"
+#define B2B_GLD(dst, reg, voff, base) asm volatile("global_load_dwordx4 %0, %1, %2" : "=" reg(dst) : "v"(voff), "s"(base) : "memory")
+
+    // ---- waits.  `s_waitcnt vmcnt(N)` waits until all but the N youngest vector-memory operations of the wave are done (loads,
+    // stores and LDS-DMA count together, in issue order) and only exists with an immediate N.  Before the barrier of step j the
+    // wave waits for EVERYTHING it has issued (vmcnt(0)): stage j+1 and, one step early, stage j+2.  Counting exactly -- a per-wave
+    // ledger of every DMA, operand load and store, so that only stage j+1 is waited for and the stores of a chunk drain under
+    // the next chunk's MFMAs -- was built and measured: 88.6 us against 86.7 us for vmcnt(0) at the 720p block-1 shape (the
+    // stores are not what the barrier waits for; the variable count needs a tree of scalar branches in front of every barrier).
+    // The epilogue operands of a chunk are waited for with a count that leaves the DMAs of the chunk's own NWN steps in flight.
+    // ---- conv3's epilogue operands: residual rows + per-channel vectors of the NEXT chunk, loaded a chunk ahead (chunk 0: at the park)
+    const bool has_res = q3.residual != nullptr, has_obn = q3.out_scale != nullptr, has_bias = q3.bias != nullptr;
+    const bool has_floor = has_obn && q3.out_floor != nullptr;
+    unsigned res_voff[4] = {0u, 0u, 0u, 0u};               // byte offsets of this wave's four residual rows (per tile)
+    const unsigned vec_voff = (unsigned)((wn * 32 + (lane & 7) * 4) * 4);
+    auto epi_rows_setup = [&](int m0) {                    // once per tile (the residual may be strided: two divisions per row)
+        if (!has_res) return;
+        const bool res_plain = q3.res_stride == 1 && q3.res_H == q3.Ho && q3.res_W == q3.Wo;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int m = min(m0 + wm * 32 + (lane >> 3) + 8 * qq, q3.M - 1);
+            unsigned roff;
+            if (res_plain) {
+                roff = (unsigned)(m * q3.res_ld);
+            } else {
+                const int img = sn_fastdiv(m, q3.div_hw_mul, q3.div_hw_shift);
+                const int rr2 = m - img * (q3.Ho * q3.Wo);
+                const int oy = sn_fastdiv(rr2, q3.div_w_mul, q3.div_w_shift), ox = rr2 - oy * q3.Wo;
+                roff = (unsigned)(((img * q3.res_H + oy * q3.res_stride) * q3.res_W + ox * q3.res_stride) * q3.res_ld);
+            }
+            res_voff[qq] = roff * 4u + vec_voff;
         }
-#undef B2B_VM
     };
-    // Before the barrier of step j: stage j+1 must have landed.  Issue order behind its DMAs (step j-2): the epilogue of step j-2,
-    // stage j+2's DMAs (step j-1), the epilogue of step j-1.  `cs` already names step j+1 here.
-    auto wait_next_stage = [&]() {
-        if (remaining > 1) {
-            int i2 = cs + 1;                               // stage j+2's index in its tile
-            if (i2 >= T) i2 -= T;
-            vm_wait(epi_prev2 + (i2 < S2 ? CNT2 : CNT3) + epi_prev);
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    B2bEpiOperands eo;
+    eo.bv = eo.os = eo.ob = eo.fl = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) eo.rv[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto epi_prefetch = [&](int n0) {                      // (uniform branches; every load is one inline-asm instruction: counted exactly)
+        if (B2B_ABLATE & 1) return;
+        if (has_res) {
+            const float* rb = q3.residual + n0;
+            B2B_GLD(eo.rv[0], B2B_RV0, res_voff[0], rb); B2B_GLD(eo.rv[1], B2B_RV1, res_voff[1], rb);
+            B2B_GLD(eo.rv[2], B2B_RV2, res_voff[2], rb); B2B_GLD(eo.rv[3], B2B_RV3, res_voff[3], rb);
         }
+        if (has_bias) { const float* b = q3.bias + n0; B2B_GLD(eo.bv, B2B_RBV, vec_voff, b); }
+        if (has_obn) {
+            const float* b1 = q3.out_scale + n0; const float* b2 = q3.out_shift + n0;
+            B2B_GLD(eo.os, B2B_ROS, vec_voff, b1); B2B_GLD(eo.ob, B2B_ROB, vec_voff, b2);
+        }
+        if (has_floor) { const float* b = q3.out_floor + n0; B2B_GLD(eo.fl, B2B_RFL, vec_voff, b); }
     };
 
     f32x4 a0, b0, a1, b1;
@@ -329,30 +353,34 @@ __global__ __launch_bounds__(128 * NWN) void conv_b2b_f32_kernel(const B2bArgs P
     issue(1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT2) : "memory");        // stage 0 landed (stage 1's DMAs may be in flight)
     B2B_BARRIER();
-    B2B_STAMP_AT(1);
     issue(2);
     B2B_RD(a0, SN_RA0, a_frag[0], 0);
     B2B_RD(b0, SN_RB0, b_frag[0], 0);
+    // A fragments of the CURRENT step live at a_frag[kk] + aoff: a ring slot (conv2) or a K-step of the park (conv3).  One step
+    // body serves both phases (conv3 runs transposed as well); every fragment read below is UNCONDITIONAL: a read that is only
+    // issued on some paths makes the compiler merge the pinned fragment registers with their previous contents through
+    // register copies -- copies of registers whose ds_read is still in flight (seen in the ISA of a first version).
+    constexpr unsigned PARK_REL = 3u * STAGE_BYTES;
+    unsigned aoff = 0;
 
-    // ---- phase 0: one K-step of conv2 on ring slot SLOT (transposed accumulators)
-    auto step2 = [&](auto slot_c) -> bool {
+    auto step = [&](auto slot_c) -> bool {
         constexpr int SLOT = decltype(slot_c)::value;
         constexpr int OFF = SLOT * STAGE_BYTES, OFF_NEXT = ((SLOT + 1) % 3) * STAGE_BYTES;
         B2B_WAIT0();
         B2B_MFT(a0, b0, x);
-        B2B_RD(a1, SN_RA1, a_frag[1], OFF); B2B_RD(b1, SN_RB1, b_frag[1], OFF);
+        { const unsigned ad = a_frag[1] + aoff; B2B_RD(a1, SN_RA1, ad, 0); } B2B_RD(b1, SN_RB1, b_frag[1], OFF);
         B2B_MFT(a0, b0, y);
         B2B_MFT(a0, b0, z);
         B2B_MFT(a0, b0, w);
         B2B_WAIT1();
         B2B_MFT(a1, b1, x);
-        B2B_RD(a0, SN_RA0, a_frag[2], OFF); B2B_RD(b0, SN_RB0, b_frag[2], OFF);
+        { const unsigned ad = a_frag[2] + aoff; B2B_RD(a0, SN_RA0, ad, 0); } B2B_RD(b0, SN_RB0, b_frag[2], OFF);
         B2B_MFT(a1, b1, y);
         B2B_MFT(a1, b1, z);
         B2B_MFT(a1, b1, w);
         B2B_WAIT0();
         B2B_MFT(a0, b0, x);
-        B2B_RD(a1, SN_RA1, a_frag[3], OFF); B2B_RD(b1, SN_RB1, b_frag[3], OFF);
+        { const unsigned ad = a_frag[3] + aoff; B2B_RD(a1, SN_RA1, ad, 0); } B2B_RD(b1, SN_RB1, b_frag[3], OFF);
         B2B_MFT(a0, b0, y);
         B2B_MFT(a0, b0, z);
         B2B_MFT(a0, b0, w);
@@ -360,23 +388,32 @@ __global__ __launch_bounds__(128 * NWN) void conv_b2b_f32_kernel(const B2bArgs P
         B2B_MFT(a1, b1, x);
         --remaining;
         ++cs;
-        const bool to_conv3 = cs == S2;                    // (remaining > 0 here: conv3 steps of this tile follow)
-        wait_next_stage();
-        B2B_BARRIER();                                     // publishes stage j+1, retires slot SLOT
-        B2B_RD(b0, SN_RB0, b_frag[0], OFF_NEXT);
-        if (!to_conv3) B2B_RD(a0, SN_RA0, a_frag[0], OFF_NEXT);
-        issue_part(SLOT, 0); __builtin_amdgcn_sched_barrier(0);           // stage j+3 into the slot just retired
+        const int j3 = cs - S2;                            // conv3 steps of this tile done so far (<= 0: still in conv2)
+        const bool park_now = j3 == 0;                     // that was conv2's last step
+        const bool chunk_done = j3 > 0 && (j3 % NWN) == 0;
+        const int n0 = ((j3 - 1) / NWN) * BN2;             // chunk_done: the chunk's first output channel
+        const int m0 = ct * BM;
+        if (cs == T) { cs = 0; ct += t_stride; }
+        const bool more = remaining > 0;
+        const unsigned aoff_next = (cs < S2) ? (unsigned)OFF_NEXT : PARK_REL + (unsigned)(((cs - S2) % NWN) * A_BYTES);
+        const unsigned ad0 = a_frag[0] + aoff_next;
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of stage j+1 (and j+2) has landed
+            B2B_BARRIER();                                 // publishes stage j+1, retires slot SLOT
+        }
+        B2B_RD(b0, SN_RB0, b_frag[0], OFF_NEXT);           // (harmless after the last step and, for a0, before the park is written)
+        B2B_RD(a0, SN_RA0, ad0, 0);
+        aoff = aoff_next;
+        const bool fed = pt < t_end;                       // stage j+3 into the slot just retired (nothing once the producer is through)
+        issue_part(SLOT, 0); __builtin_amdgcn_sched_barrier(0);
         B2B_MFT(a1, b1, y);
         issue_part(SLOT, 1); __builtin_amdgcn_sched_barrier(0);
         B2B_MFT(a1, b1, z);
         issue_part(SLOT, 2); __builtin_amdgcn_sched_barrier(0);
         B2B_MFT(a1, b1, w);
         issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0);
-        epi_prev2 = epi_prev;
-        epi_prev = 0;
-        if (to_conv3) {
-            B2B_WAIT0();                                   // conv3's first B fragment: landed before the code below
-            B2B_STAMP_AT(2);
+        if (park_now && !(B2B_ABLATE & 4)) {
+            B2B_WAIT0();                                   // the reads above: landed before the code below
             // park: relu(bn2(acc^T)) as NWN A stages.  Lane (m, h), quad q -> row wm*32 + m, chunk 2q + h of K-step wn.
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
@@ -387,72 +424,26 @@ __global__ __launch_bounds__(128 * NWN) void conv_b2b_f32_kernel(const B2bArgs P
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             B2B_BARRIER();                                 // the whole tile is parked
-            B2B_RD(a0, SN_RA0, p_frag[0], 0);
+            B2B_RD(a0, SN_RA0, ad0, 0);                    // conv3's first A fragment, now that it exists
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            epi_rows_setup(m0);
+            epi_prefetch(0);                               // chunk 0's epilogue operands: NWN steps ahead of their use
         }
-        return true;
-    };
-
-    // ---- phase 1: one K-step of conv3 (A from the park, B from ring slot SLOT)
-    auto step3 = [&](auto slot_c) -> bool {
-        constexpr int SLOT = decltype(slot_c)::value;
-        constexpr int OFF = SLOT * STAGE_BYTES, OFF_NEXT = ((SLOT + 1) % 3) * STAGE_BYTES;
-        const int j3 = cs - S2;                            // conv3 step index: chunk j3 / NWN, K-step j3 % NWN
-        const unsigned pa = (unsigned)((j3 % NWN) * A_BYTES);
-        B2B_WAIT0();
-        B2B_MF(a0, b0, x);
-        { const unsigned ad = p_frag[1] + pa; B2B_RD(a1, SN_RA1, ad, 0); } B2B_RD(b1, SN_RB1, b_frag[1], OFF);
-        B2B_MF(a0, b0, y);
-        B2B_MF(a0, b0, z);
-        B2B_MF(a0, b0, w);
-        B2B_WAIT1();
-        B2B_MF(a1, b1, x);
-        { const unsigned ad = p_frag[2] + pa; B2B_RD(a0, SN_RA0, ad, 0); } B2B_RD(b0, SN_RB0, b_frag[2], OFF);
-        B2B_MF(a1, b1, y);
-        B2B_MF(a1, b1, z);
-        B2B_MF(a1, b1, w);
-        B2B_WAIT0();
-        B2B_MF(a0, b0, x);
-        { const unsigned ad = p_frag[3] + pa; B2B_RD(a1, SN_RA1, ad, 0); } B2B_RD(b1, SN_RB1, b_frag[3], OFF);
-        B2B_MF(a0, b0, y);
-        B2B_MF(a0, b0, z);
-        B2B_MF(a0, b0, w);
-        B2B_WAIT1();
-        B2B_MF(a1, b1, x);
-        --remaining;
-        ++cs;
-        const bool chunk_done = ((j3 + 1) % NWN) == 0;
-        const bool tile_done = cs == T;
-        const int n0 = (j3 / NWN) * BN2;                   // the chunk's first output channel
-        const int m0 = ct * BM;
-        const bool more = remaining > 0;
-        if (tile_done) { cs = 0; ct += t_stride; }
-        if (more) {
-            wait_next_stage();
-            B2B_BARRIER();
-            B2B_RD(b0, SN_RB0, b_frag[0], OFF_NEXT);
-            if (tile_done) {
-                B2B_RD(a0, SN_RA0, a_frag[0], OFF_NEXT);   // the next tile's first conv2 stage
-            } else {
-                const unsigned ad = p_frag[0] + (chunk_done ? 0u : pa + (unsigned)A_BYTES);
-                B2B_RD(a0, SN_RA0, ad, 0);
-            }
-        }
-        issue_part(SLOT, 0); __builtin_amdgcn_sched_barrier(0);
-        B2B_MF(a1, b1, y);
-        issue_part(SLOT, 1); __builtin_amdgcn_sched_barrier(0);
-        B2B_MF(a1, b1, z);
-        issue_part(SLOT, 2); __builtin_amdgcn_sched_barrier(0);
-        B2B_MF(a1, b1, w);
-        issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0);
-        epi_prev2 = epi_prev;
-        epi_prev = 0;
-        if (chunk_done) {
-            if (more) B2B_WAIT0();                         // the next step's first fragments: landed before the epilogue code
-            B2B_STAMP_AT(3);
-            b2b_chunk_epilogue(acc, q3, m0 + wm * 32, n0 + wn * 32, lane, scr_base);
-            if (m0 + BM <= q3.M) epi_prev = P.epi_vmem;    // (a ragged tile may skip stores: counted as zero -> the next wait is strict)
+        if (chunk_done && !(B2B_ABLATE & 2)) {
+            B2B_WAIT0();                                   // the next step's first fragments: landed before the epilogue code
+            // the operands fetched a chunk ago: younger than their loads are at least the 2 DMAs of each of this chunk's NWN
+            // steps (as long as the producer had stages left) -- those stay in flight
+            if (fed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWN) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+" B2B_RV0(eo.rv[0]), "+" B2B_RV1(eo.rv[1]), "+" B2B_RV2(eo.rv[2]), "+" B2B_RV3(eo.rv[3]),
+                              "+" B2B_RBV(eo.bv), "+" B2B_ROS(eo.os), "+" B2B_ROB(eo.ob), "+" B2B_RFL(eo.fl));
+            f32x4 outv[4];
+            b2b_chunk_compute(acc, q3, lane, scr_base, eo, outv);
+            // the NEXT chunk's operands go out BEFORE this chunk's stores (the operand registers are free again): vmcnt retires
+            // in issue order, so a later wait for those loads does not have to sit out the stores
+            if (j3 < S3) epi_prefetch(n0 + BN2);
+            b2b_chunk_store(outv, q3, m0 + wm * 32, n0 + wn * 32, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         }
@@ -463,15 +454,14 @@ __global__ __launch_bounds__(128 * NWN) void conv_b2b_f32_kernel(const B2bArgs P
     using s1 = std::integral_constant<int, 1>;
     using s2 = std::integral_constant<int, 2>;
     while (true) {
-        if (!(cs < S2 ? step2(s0{}) : step3(s0{}))) break;
-        if (!(cs < S2 ? step2(s1{}) : step3(s1{}))) break;
-        if (!(cs < S2 ? step2(s2{}) : step3(s2{}))) break;
+        if (!step(s0{})) break;
+        if (!step(s1{})) break;
+        if (!step(s2{})) break;
     }
-    B2B_STAMP_AT(4);
 #undef B2B_RD
 #undef B2B_WAIT0
 #undef B2B_WAIT1
-#undef B2B_MF
 #undef B2B_MFT
 #undef B2B_BARRIER
+#undef B2B_GLD
 }

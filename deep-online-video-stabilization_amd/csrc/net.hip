@@ -375,10 +375,21 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             }
             // Inference plan, block 1 / block 2 units with enough 64-pixel tiles to fill the chip: conv2 and conv3 as ONE launch
             // (conv_b2b_kernel.h): the activated conv2 tile stays in LDS, the low-K conv3 launch and the round trip of its input go.
+            // OFF by default (STABNET_CONV_B2B_PLAN=1 turns it on): measured in the 720p frame (same box, same build) every choice
+            // of units loses to the two launches -- all six eligible units 541.5 against 554.3 frames/s, the three 225-tile
+            // units of block 1 / block 2 545.5, block 1's strided unit alone 551.6 (the fused
+            // launch has no more matrix throughput per step than the two kernels, 80 / 136 KB of LDS leave two / one workgroup per
+            // CU, and the 1x1 phase costs its 8 K-steps plus four epilogues that nothing overlaps).  The window [min_tiles,
+            // max_tiles] and the d_b mask (bit 0: 64, bit 1: 128) select units when the plan switch is on.
             if (!keep_all && i_conv2 + 2 == net->steps.size()) {
-                static const int min_tiles = []() { const char* v = getenv("STABNET_CONV_B2B_MIN_TILES"); return v ? atoi(v) : 200; }();
+                auto env = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+                static const int plan_on = env("STABNET_CONV_B2B_PLAN", 0);
+                static const int min_tiles = env("STABNET_CONV_B2B_MIN_TILES", 200), max_tiles = env("STABNET_CONV_B2B_MAX_TILES", 1 << 30);
+                static const int cmask = env("STABNET_CONV_B2B_CMASK", 3);
                 const Step c2 = net->steps[i_conv2], c3 = net->steps[i_conv2 + 1];
-                if (conv_b2b_supported(c2.conv, c3.conv) && (c3.conv.M + 63) / 64 >= min_tiles) {
+                const int tiles = (c3.conv.M + 63) / 64;
+                if (plan_on && conv_b2b_supported(c2.conv, c3.conv) && tiles >= min_tiles && tiles <= max_tiles &&
+                    ((c2.conv.Cout == 64 && (cmask & 1)) || (c2.conv.Cout == 128 && (cmask & 2)))) {
                     Step f = c2;
                     f.kind = S_CONV_B2B;
                     f.conv_b = c3.conv;

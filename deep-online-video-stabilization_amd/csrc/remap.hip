@@ -2,8 +2,9 @@
 // The reference does this on the host with OpenCV after every sess.run; here the maps never leave the device:
 //   map_shrink_kernel : cv2.resize(map, (W/rate, H/rate)) INTER_LINEAR (half-pixel centres, float32, h-pass then v-pass)
 //   remap_color_kernel: cv2.resize back to (W, H) fused with (m+1)/2*size and cv2.remap(..., INTER_LINEAR) on the uint8
-//                       BGR frame (coordinates quantised to 1/32 px like OpenCV, BORDER_CONSTANT 0)
-// Float32 op order as oracle/stabnet_oracle.py: cv_resize_linear_f32 / cv_remap_linear_u8 (-ffp-contract=off).  HBM-bound:
+//                       BGR frame: OpenCV's FIXED-POINT bilinear path (1/32 px coordinates, 15-bit integer weight table,
+//                       (sum + 16384) >> 15), BORDER_CONSTANT 0 -- integer arithmetic, bit-exact against the oracle
+// Float32 op order of the two resizes as oracle/stabnet_oracle.py: cv_resize_linear_f32 (-ffp-contract=off).  HBM-bound:
 // per frame 8*H*W (maps in) + 3*H*W (frame, gathered) + 3*H*W (out) bytes.
 #include "common.h"
 
@@ -51,19 +52,26 @@ __global__ __launch_bounds__(256) void remap_color_kernel(const unsigned char* _
     const float px = (xs + 1.0f) / 2.0f * (float)W;                 // deploy_bundle.py:142-143
     const float py = (ys + 1.0f) / 2.0f * (float)H;
     if (px_out != nullptr) { px_out[(size_t)n * H * W + q] = px; py_out[(size_t)n * H * W + q] = py; }
-    const long sx = (long)rintf(px * 32.0f), sy = (long)rintf(py * 32.0f);      // cvRound: half to even
-    const long ix = sx >> 5, iy = sy >> 5;
-    const float fx = (float)(sx & 31) / 32.0f, fy = (float)(sy & 31) / 32.0f;
-    const float w00 = (1.0f - fx) * (1.0f - fy), w01 = fx * (1.0f - fy), w10 = (1.0f - fx) * fy, w11 = fx * fy;
+    // OpenCV's 8-bit bilinear remap (imgwarp.cpp: RemapInvoker + remapBilinear<FixedPtCast<int, uchar, 15>, RemapVec_8u, short>;
+    // oracle cv_remap_linear_u8 / cv_bilinear_tab_i): coordinates quantised to 1/32 px (cvRound: half to even), integer part
+    // saturated to int16, 15-bit integer weights wy[k1] * wx[k2] * 32768 -- all exact multiples of 32 except the table's entry
+    // (0, 0), whose weight 1.0 saturates to 32767 and whose repair loop puts the missing 1 on tap [1][1] -- integer accumulate,
+    // (sum + 16384) >> 15.  (A float beyond the int range is out of frame either way: clamped before the conversion.)
+    const float qx = fminf(fmaxf(px * 32.0f, -2.0e9f), 2.0e9f), qy = fminf(fmaxf(py * 32.0f, -2.0e9f), 2.0e9f);
+    const int sx = (qx == qx) ? (int)rintf(qx) : -2000000000, sy = (qy == qy) ? (int)rintf(qy) : -2000000000;
+    const int ix = min(max(sx >> 5, -32768), 32767), iy = min(max(sy >> 5, -32768), 32767);
+    const int fx = sx & 31, fy = sy & 31;
+    int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+    if ((fx | fy) == 0) { w00 = 32767; w11 = 1; }
     const unsigned char* im = img + (size_t)n * H * W * C;
     const bool x0 = ix >= 0 && ix < W, x1 = ix + 1 >= 0 && ix + 1 < W, y0 = iy >= 0 && iy < H, y1 = iy + 1 >= 0 && iy + 1 < H;
     for (int c = 0; c < C; ++c) {
-        const float v00 = (x0 && y0) ? (float)im[((size_t)iy * W + ix) * C + c] : 0.f;
-        const float v01 = (x1 && y0) ? (float)im[((size_t)iy * W + ix + 1) * C + c] : 0.f;
-        const float v10 = (x0 && y1) ? (float)im[((size_t)(iy + 1) * W + ix) * C + c] : 0.f;
-        const float v11 = (x1 && y1) ? (float)im[((size_t)(iy + 1) * W + ix + 1) * C + c] : 0.f;
-        const float acc = ((v00 * w00 + v01 * w01) + v10 * w10) + v11 * w11;
-        out[((size_t)n * H * W + q) * C + c] = (unsigned char)fminf(fmaxf(rintf(acc), 0.f), 255.f);
+        const int v00 = (x0 && y0) ? (int)im[((size_t)iy * W + ix) * C + c] : 0;
+        const int v01 = (x1 && y0) ? (int)im[((size_t)iy * W + ix + 1) * C + c] : 0;
+        const int v10 = (x0 && y1) ? (int)im[((size_t)(iy + 1) * W + ix) * C + c] : 0;
+        const int v11 = (x1 && y1) ? (int)im[((size_t)(iy + 1) * W + ix + 1) * C + c] : 0;
+        const int acc = (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15;
+        out[((size_t)n * H * W + q) * C + c] = (unsigned char)min(max(acc, 0), 255);
     }
 }
 

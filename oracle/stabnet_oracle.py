@@ -710,30 +710,84 @@ def cv_resize_linear_f32(src, dw, dh):
     return rows[y0, :] * by0[:, None] + rows[y1, :] * by1[:, None]
 
 
+_CV_INTER_BITS = 5
+_CV_INTER_TAB_SIZE = 1 << _CV_INTER_BITS                 # 32 sub-pixel positions per axis
+_CV_REMAP_COEF_BITS = 15
+_CV_REMAP_COEF_SCALE = 1 << _CV_REMAP_COEF_BITS          # 32768
+_cv_bilinear_tab_cache = None
+
+
+def cv_bilinear_tab_i():
+    """[external] OpenCV's fixed-point bilinear weight table BilinearTab_i[32*32][2][2] (imgproc/imgwarp.cpp,
+    initInterTab2D(INTER_LINEAR, fixpt=true)), restated from the published source, literally -- including its two quirks:
+    entry (fy, fx) holds saturate_cast<short>(wy[k1] * wx[k2] * 32768) for the four taps (k1 = row, k2 = column) with
+    wy = (1 - fy/32, fy/32); every product is an exact multiple of 32 EXCEPT the weight 1.0 of entry (0, 0), which saturates to
+    32767; entries whose sum is not 32768 are repaired by the bicubic-shaped loop `for k1, k2 in {ksize/2, ksize/2 + 1}`, which for
+    ksize = 2 walks flat indices 3, 4, 5, 6 (its own last tap and the first three taps of the NEXT entry, still zero at that point
+    of the one-time initialisation) and therefore adds the missing 1 to tap [1][1]: entry (0, 0) = {32767, 0, 0, 1}.
+    -> int64 [1024, 4] (tap order [0][0], [0][1], [1][0], [1][1]; index = fy * 32 + fx)."""
+    global _cv_bilinear_tab_cache
+    if _cv_bilinear_tab_cache is not None:
+        return _cv_bilinear_tab_cache
+    n, ks = _CV_INTER_TAB_SIZE, 2
+    scale = F(1.0) / F(n)
+    tab1 = [(F(1.0) - F(i) * scale, F(i) * scale) for i in range(n)]          # interpolateLinear(i * scale)
+    flat = np.zeros(n * n * ks * ks + 8, np.int64)                            # static storage: zero-initialised
+    for i in range(n):
+        for j in range(n):
+            base = (i * n + j) * ks * ks
+            isum = 0
+            for k1 in range(ks):
+                vy = tab1[i][k1]
+                for k2 in range(ks):
+                    v = F(vy * tab1[j][k2])
+                    iv = int(np.clip(np.rint(np.float64(F(v * F(_CV_REMAP_COEF_SCALE)))), -32768, 32767))   # saturate_cast<short>
+                    flat[base + k1 * ks + k2] = iv
+                    isum += iv
+            if isum != _CV_REMAP_COEF_SCALE:
+                diff = isum - _CV_REMAP_COEF_SCALE
+                k0 = ks // 2
+                Mk = mk = (k0, k0)
+                for k1 in range(k0, k0 + 2):
+                    for k2 in range(k0, k0 + 2):
+                        if flat[base + k1 * ks + k2] < flat[base + mk[0] * ks + mk[1]]:
+                            mk = (k1, k2)
+                        elif flat[base + k1 * ks + k2] > flat[base + Mk[0] * ks + Mk[1]]:
+                            Mk = (k1, k2)
+                if diff < 0:
+                    flat[base + Mk[0] * ks + Mk[1]] -= diff
+                else:
+                    flat[base + mk[0] * ks + mk[1]] -= diff
+    _cv_bilinear_tab_cache = flat[:n * n * ks * ks].reshape(n * n, ks * ks).copy()
+    return _cv_bilinear_tab_cache
+
+
 def cv_remap_linear_u8(img, map_x, map_y):
-    """[external] cv2.remap(img_u8, map_x, map_y, INTER_LINEAR), BORDER_CONSTANT 0, restated: coordinates are quantised
-    to 1/32 pixel (sx = cvRound(x*32), integer part sx >> 5, fraction (sx & 31)/32) as OpenCV does.  NOT reproduced:
-    OpenCV's 15-bit fixed-point weight table (its rounding differs from float weights by < 0.02 grey levels, so results
-    can differ by one grey level on exact .5 ties)."""
+    """[external] cv2.remap(img_u8, map_x, map_y, INTER_LINEAR) with float32 maps, BORDER_CONSTANT 0 (deploy_bundle.py:144),
+    restated from OpenCV's published algorithm (imgproc/imgwarp.cpp: RemapInvoker + remapBilinear<FixedPtCast<int, uchar, 15>,
+    RemapVec_8u, short>): coordinates are quantised to 1/32 pixel, sx = cvRound(x * 32) (float32 product, half to even),
+    integer part saturate_cast<short>(sx >> 5), table index (sy & 31) * 32 + (sx & 31); the four taps (out-of-frame taps read
+    the border value 0) are blended with the 15-bit integer weights of cv_bilinear_tab_i() and the sum is rounded as
+    (sum + 16384) >> 15, saturated to uint8.  Integer arithmetic throughout: bit-exact by construction."""
     img = np.asarray(img, np.uint8)
     H, W, C = img.shape
-    sx = np.rint(_f(map_x) * F(32)).astype(np.int64)
-    sy = np.rint(_f(map_y) * F(32)).astype(np.int64)
-    ix, iy = sx >> 5, sy >> 5
-    fx = ((sx & 31).astype(F)) / F(32)
-    fy = ((sy & 31).astype(F)) / F(32)
+    # (cvRound of a float beyond the int range is INT_MIN on x86; such a coordinate is out of frame either way: clamp first)
+    qx = np.clip(_f(map_x) * F(_CV_INTER_TAB_SIZE), F(-2.0e9), F(2.0e9))
+    qy = np.clip(_f(map_y) * F(_CV_INTER_TAB_SIZE), F(-2.0e9), F(2.0e9))
+    sx = np.rint(np.nan_to_num(qx, nan=-2.0e9)).astype(np.int64)
+    sy = np.rint(np.nan_to_num(qy, nan=-2.0e9)).astype(np.int64)
+    ix = np.clip(sx >> _CV_INTER_BITS, -32768, 32767)                          # saturate_cast<short>
+    iy = np.clip(sy >> _CV_INTER_BITS, -32768, 32767)
+    wtab = cv_bilinear_tab_i()[(sy & 31) * _CV_INTER_TAB_SIZE + (sx & 31)]       # [h, w, 4]
 
     def tap(yy, xx):
         ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
-        v = img[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)].astype(F)
-        return np.where(ok[..., None], v, F(0))
+        v = img[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)].astype(np.int64)
+        return np.where(ok[..., None], v, 0)
 
-    w00 = ((F(1) - fx) * (F(1) - fy))[..., None]
-    w01 = (fx * (F(1) - fy))[..., None]
-    w10 = ((F(1) - fx) * fy)[..., None]
-    w11 = (fx * fy)[..., None]
-    acc = ((tap(iy, ix) * w00 + tap(iy, ix + 1) * w01) + tap(iy + 1, ix) * w10) + tap(iy + 1, ix + 1) * w11
-    return np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+    acc = (tap(iy, ix) * wtab[..., 0:1] + tap(iy, ix + 1) * wtab[..., 1:2] + tap(iy + 1, ix) * wtab[..., 2:3]
+           + tap(iy + 1, ix + 1) * wtab[..., 3:4])
+    return np.clip((acc + (1 << (_CV_REMAP_COEF_BITS - 1))) >> _CV_REMAP_COEF_BITS, 0, 255).astype(np.uint8)
 
 
 def warpRevBundle2(img, x_map, y_map, rate=4):
