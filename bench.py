@@ -33,8 +33,8 @@ PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 frames; --mode train: 50 optimiser steps, SURVEY 8d)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 20; --mode train: 10)")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--streams", type=int, default=1, help="streams per GPU stepped in lock-step (batch of the net)")
@@ -49,11 +49,19 @@ def parse():
     ap.add_argument("--train-batch", type=int, default=8, help="pairs per GPU (weak scaling)")
     ap.add_argument("--train-height", type=int, default=288)
     ap.add_argument("--train-width", type=int, default=512)
-    ap.add_argument("--train-steps", type=int, default=10, help="steps of the extra train leg of the default run")
+    ap.add_argument("--train-steps", type=int, default=30, help="steps of the extra train leg of the default run (5 warm-up steps)")
     ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the frame eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the SECONDARY bf16-operand line (never the headline)")
-    return ap.parse_args()
+    ap.add_argument("--dump-event-raw", default=None, metavar="JSON",
+                    help="write {kernel: raw HIP-event average} of the instrumented pass (tools/profile_stamp.py calibrates the "
+                         "per-kernel event offsets against rocprofv3 with it)")
+    a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 50 if a.mode == "train" else 200
+    if a.warmup is None:
+        a.warmup = 10 if a.mode == "train" else 20
+    return a
 
 
 def csrc_sha16():
@@ -173,47 +181,98 @@ def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
         psteps = max(1, min(steps // 2, 3))
         prof = Profiler(max_records=psteps * 2000, device=dev)
         prof.calibrate()
+        tab, note = load_kernel_profile((N, H, W) == (8, 288, 512), PMC_FILE_TRAIN)
+        prof.set_offsets(event_offsets(tab))
         tr.prof = prof
         for _ in range(psteps):
             tr.forward_backward(dev_b, gates)
         roof, table = roofline_from_records(prof.records(), psteps)
+        raw_table = roofline_from_records(prof.records(raw=True), psteps)[1]
         tr.prof = None
         if rank == 0:
             roof["whole_step_tflops"] = out["step_gflop_algorithmic"] / out["ms_per_step"]
             roof["whole_step_frac"] = roof["whole_step_tflops"] / PEAK_F32_MFMA_TFLOPS
-            roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], (N, H, W) == (8, 288, 512), PMC_FILE_TRAIN)
+            annotate_roofline(roof, tab, note, prof)
             out["roofline"] = roof
             out["kernels"] = table[:6]
+            out["event_raw"] = {r["kernel"]: {"raw_avg_us": r["avg_us"], "launches": r["launches_per_frame"]} for r in raw_table}
     return out
 
 
-PMC_FILE = os.path.join("profiles", "r03_pmc_hbm_traffic_bench720p.json")
-PMC_FILE_TRAIN = os.path.join("profiles", "r03_pmc_hbm_traffic_train_b8.json")
-PMC_FILE_1080P = os.path.join("profiles", "r03_pmc_hbm_traffic_bench1080p.json")       # BASELINE configs[4] shape on one GPU
+PMC_FILE = os.path.join("profiles", "r04_kernel_profile_bench720p.json")
+PMC_FILE_TRAIN = os.path.join("profiles", "r04_kernel_profile_train_b8.json")
+PMC_FILE_1080P = os.path.join("profiles", "r04_kernel_profile_bench1080p.json")       # BASELINE configs[4] shape on one GPU
 
 
-def pmc_traffic(kernel, workload_is_default, pmc_file=None):
-    """(HBM bytes per launch of `kernel`, note) from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected
-    in separate runs of this same command, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  Only valid for the
-    default 720p workload AND for the kernel sources the passes were taken on (the file carries their hash): otherwise
-    (None, why)."""
-    PMC_FILE = pmc_file or globals()["PMC_FILE"]
-    path = os.path.join(ROOT, PMC_FILE)
+def load_kernel_profile(workload_is_default, pmc_file=None):
+    """(table, note): the stamped per-kernel profile of this workload (tools/profile_stamp.py: rocprofv3 --pmc passes, rocprofv3
+    --stats averages and the HIP-event offsets calibrated against them, all taken with this same command) -- or (None, why)
+    when the workload is not a BASELINE one, the file is missing, or it was taken on other kernel sources (hash of csrc/)."""
+    pmc_file = pmc_file or PMC_FILE
+    path = os.path.join(ROOT, pmc_file)
     if not workload_is_default:
-        return None, "PMC passes exist for the BASELINE workloads only (720p / 1080p batch 1; training 8 pairs at 288x512)"
+        return None, "profiles exist for the BASELINE workloads only (720p / 1080p batch 1; training 8 pairs at 288x512)"
     if not os.path.exists(path):
-        return None, "no %s (run tools/refresh_profiles.sh on the GPU box)" % PMC_FILE
+        return None, "no %s (run tools/refresh_profiles.sh on the GPU box)" % pmc_file
     try:
         tab = json.load(open(path))
     except Exception as e:
-        return None, "unreadable %s: %s" % (PMC_FILE, e)
+        return None, "unreadable %s: %s" % (pmc_file, e)
     stamp = tab.get("__meta__", {}).get("csrc_sha16")
     if stamp != csrc_sha16():
-        return None, "%s was taken on kernel sources %s, this build is %s: stale, not reported" % (PMC_FILE, stamp, csrc_sha16())
+        return None, "%s was taken on kernel sources %s, this build is %s: stale, not used" % (pmc_file, stamp, csrc_sha16())
+    return tab, "%s (csrc %s)" % (pmc_file, stamp)
+
+
+def profile_entry(tab, kernel):
+    """The profile's entry of a kernel named as the library's profiler names it (some carry no template arguments there)."""
+    if not tab:
+        return None
+    best = None
     for k, v in tab.items():
-        if k.replace("void ", "").split("(")[0] == kernel:
-            return v["hbm_bytes_per_launch_corrected"], "%s (rocprofv3 --pmc, separate passes; csrc %s)" % (PMC_FILE, stamp)
-    return None, "kernel %s not in %s" % (kernel, PMC_FILE)
+        if k == "__meta__":
+            continue
+        if k == kernel or v.get("hip_event_name") == kernel:
+            return v
+        if k.startswith(kernel + "<") and (best is None or v.get("rocprofv3_calls", 0) > best.get("rocprofv3_calls", 0)):
+            best = v
+    return best
+
+
+def event_offsets(tab):
+    """{library profiler kernel name: us} from the stamped profile (empty without one)."""
+    out = {}
+    for k, v in (tab or {}).items():
+        if k != "__meta__" and "hip_event_offset_us" in v:
+            out[v.get("hip_event_name", k)] = max(0.0, float(v["hip_event_offset_us"]))
+    return out
+
+
+def annotate_roofline(roof, tab, note, prof, algorithmic_bytes=None):
+    """traffic (+ what the counter is, + the algorithmic bytes beside it), the event offset that was subtracted and rocprofv3's
+    own figure for the same kernel on the same build."""
+    e = profile_entry(tab, roof["kernel"])
+    roof["traffic"] = e.get("l2_fabric_bytes_per_launch") if e else None
+    roof["traffic_source"] = (note + ": rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes") if e else note
+    roof["traffic_counts"] = ("bytes per launch on the fabric side of the eight XCD L2s (TCC -> EA requests: served by the Infinity "
+                              "Cache or HBM, the counter cannot tell which) -- an upper bound of the HBM bytes")
+    if algorithmic_bytes is not None:
+        roof["algorithmic_bytes_per_launch"] = algorithmic_bytes
+    if roof.get("traffic") and roof.get("algorithmic_bytes_per_launch"):
+        roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
+    name = roof["kernel"]
+    roof["hip_event_offset_us_subtracted"] = 1e3 * prof.offset_ms(name)
+    roof["hip_event_offset_source"] = ("calibrated against the rocprofv3 average of this kernel on this build: " + note) \
+        if name in prof.offsets_us else "default: half an idle event pair (%.2f us); no stamped profile for this build / workload" % (
+            1e3 * prof.idle_pair_ms)
+    if e and "rocprofv3_avg_us" in e:
+        roof["avg_launch_us_rocprofv3"] = e["rocprofv3_avg_us"]
+        work = roof.get("algorithmic_flops_per_launch") if roof["bound"] == "mfma" else roof.get("algorithmic_bytes_per_launch")
+        if work:
+            ach = work / (e["rocprofv3_avg_us"] * 1e-6) / (1e12 if roof["bound"] == "mfma" else 1e9)
+            roof["achieved_rocprofv3"] = ach
+            roof["frac_rocprofv3"] = ach / roof["peak"]
+    return roof
 
 
 def roofline_from_records(recs, steps):
@@ -237,7 +296,7 @@ def roofline_from_records(recs, steps):
         ach = fl / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_us": 1e3 * ms / n,
-                "algorithmic_flops_per_launch": fl / n}
+                "algorithmic_flops_per_launch": fl / n, "algorithmic_bytes_per_launch": by / n}
     else:
         ach = by / (ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -410,6 +469,8 @@ def main():
             for k in ("roofline", "kernels", "loss", "tower_fwd_gflop", "comm", "step_gflop_algorithmic"):
                 if k in t:
                     line[k] = t[k]
+            if args.dump_event_raw and "event_raw" in t:
+                json.dump(t["event_raw"], open(args.dump_event_raw, "w"), indent=1)
             print(json.dumps(line))
         if dist is not None:
             dist.destroy_process_group()
@@ -457,7 +518,12 @@ def main():
     if rank == 0 and not args.no_roofline:
         # the same K steps again with an event pair around every launch (instrumentation kept out of `value`)
         prof = Profiler(max_records=args.steps * (stream.reg.plan.num_launches + 16))
-        event_overhead_ms = prof.calibrate()
+        prof.calibrate()
+        # PMC / rocprofv3 profiles exist for the two BASELINE inference shapes (720p = configs[1], 1080p = the per-GPU shape of configs[4])
+        pmc_file = {(720, 1280): PMC_FILE, (1080, 1920): PMC_FILE_1080P}.get((H, W))
+        pmc_ok = pmc_file is not None and (S, args.refine) == (1, 1)
+        ktab, knote = load_kernel_profile(pmc_ok, pmc_file)
+        prof.set_offsets(event_offsets(ktab))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
@@ -466,17 +532,19 @@ def main():
         torch.cuda.synchronize()
         prof_ms = 1e3 * (time.perf_counter() - t1) / args.steps
         roof, table = roofline_from_records(prof.records(), args.steps)
-        # PMC passes exist for the two BASELINE inference shapes (720p = configs[1], 1080p = the per-GPU shape of configs[4])
-        pmc_file = {(720, 1280): PMC_FILE, (1080, 1920): PMC_FILE_1080P}.get((H, W))
-        pmc_ok = pmc_file is not None and (S, args.refine) == (1, 1)
+        raw_table = roofline_from_records(prof.records(raw=True), args.steps)[1]
+        if args.dump_event_raw:
+            json.dump({r["kernel"]: {"raw_avg_us": r["avg_us"], "launches": r["launches_per_frame"]} for r in raw_table},
+                      open(args.dump_event_raw, "w"), indent=1)
         for row in table:                      # the HBM-bound kernel of the path: the fused map + gather warp
             if row["kernel"] == "warp_sample_kernel":
                 # sampler + feedback push in one launch: 20 HW (src, out, black, maps) + 12 HW (ring frame, ring mask, frame_fb)
-                roof_warp = {"bound": "hbm", "kernel": "warp_sample_kernel<1>", "achieved": row["gbps"], "peak": PEAK_HBM_GBPS,
+                roof_warp = {"bound": "hbm", "kernel": "warp_sample_kernel", "achieved": row["gbps"], "peak": PEAK_HBM_GBPS,
                              "unit": "GB/s", "frac": row["gbps"] / PEAK_HBM_GBPS, "avg_launch_us": row["avg_us"],
-                             "algorithmic_bytes_per_launch": S * (32.0 * H * W + 776.0),
-                             "traffic": pmc_traffic("warp_sample_kernel<1>", pmc_ok, pmc_file)[0]}
-        roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], pmc_ok, pmc_file)
+                             "algorithmic_bytes_per_launch": S * (32.0 * H * W + 776.0)}
+                annotate_roofline(roof_warp, ktab, knote, prof)
+                roof_warp["kernel"] = "warp_sample_kernel<1>"
+        annotate_roofline(roof, ktab, knote, prof)
 
     bf16 = None
     if rank == 0 and not args.no_bf16_leg:
@@ -513,7 +581,7 @@ def main():
     if not args.no_train_leg:
         del stream
         torch.cuda.empty_cache()
-        train = train_leg(args, dev, dist, rank, world, args.train_steps, 3, not args.no_roofline)
+        train = train_leg(args, dev, dist, rank, world, args.train_steps, 5, not args.no_roofline)
     peaks = empirical_peaks(dev) if (rank == 0 and not args.no_roofline) else None
 
     if dist is not None:
@@ -544,7 +612,7 @@ def main():
                 line["roofline_warp"] = roof_warp
             line["kernels"] = table[:8]
             line["instrumented_ms_per_step"] = prof_ms
-            line["roofline"]["event_pair_overhead_us_subtracted"] = 1e3 * event_overhead_ms
+            line["roofline"]["idle_event_pair_us"] = 1e3 * prof.idle_pair_ms
             line["roofline"]["whole_frame_tflops"] = plan_flops / (el / args.steps) / 1e12
             line["roofline"]["whole_frame_frac"] = line["roofline"]["whole_frame_tflops"] / PEAK_F32_MFMA_TFLOPS
         if peaks is not None:
@@ -558,6 +626,7 @@ def main():
         if bf16 is not None:
             line["secondary_bf16_operands"] = bf16
         if train is not None:
+            train.pop("event_raw", None)
             line["train"] = train          # BASELINE configs[2]/[3] measured in the same run (second metric)
         print(json.dumps(line))
     if dist is not None:

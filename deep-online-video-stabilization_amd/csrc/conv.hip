@@ -407,14 +407,16 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands
         kind = PK_KERNEL_CONV_BASE + mode * 6 + t * 2 + (bk32 ? 1 : 0) + (nbuf == 1 ? 18 : 0) + (bf16 ? 36 : 0);
     }
     if (rec) prof->end(st, kind, 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
-                       4.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.K * a.Cout + (double)a.M * a.Cout * a.splitk),
+                       // algorithmic bytes: input + weights + output (or the split-K slabs) + the residual read
+                       4.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.K * a.Cout + (double)a.M * a.Cout * (kg > 1 ? 1 : a.splitk) +
+                              ((a.residual != nullptr && (a.splitk == 1 || kg > 1)) ? (double)a.M * a.Cout : 0.0)),
                        a.M, a.Cout, a.K, a.splitk);
     if (rc) return rc;
     if (a.splitk > 1 && kg == 1) {
         const size_t q = (size_t)a.M * (a.Cout / 4);
         const bool rec2 = prof != nullptr && prof->begin(st);
         conv_splitk_reduce_kernel<<<cdiv((long)q, 256), 256, 0, st>>>(a);
-        if (rec2) prof->end(st, PK_KERNEL_SPLITK_REDUCE, 0.0, 4.0 * (double)a.M * a.Cout * (a.splitk + 1));
+        if (rec2) prof->end(st, PK_KERNEL_SPLITK_REDUCE, 0.0, 4.0 * (double)a.M * a.Cout * (a.splitk + 1 + (a.residual != nullptr ? 1 : 0)));
         SN_LAUNCH_CHECK("conv_splitk_reduce_kernel");
     }
     return STABNET_OK;
