@@ -238,6 +238,11 @@ static bool ring_eligible(const ConvArgs& a, int tile, bool has_prologue) {
 static bool ring_eligible(const ConvArgs& a, int tile) { return ring_eligible(a, tile, a.in_scale != nullptr); }
 
 static int g_ring_wgs = 0;        // resident workgroups of the ring kernel on this device (3 per CU: 48 KiB LDS each)
+static int g_ring_cus = 0;        // (the CU count g_ring_wgs was computed from)
+static int g_reserved_cus = 0;    // CUs the persistent grids leave to a communication stream (stabnet_conv_reserve_cus)
+// persistent grids are sized for the CUs that are NOT reserved (never fewer than an eighth of the chip)
+static int usable_cus(int cus) { return std::max(cus / 8, cus - std::max(0, g_reserved_cus)); }
+static int ring_grid_cap() { return g_ring_cus > 0 ? g_ring_wgs / g_ring_cus * usable_cus(g_ring_cus) : g_ring_wgs; }
 
 template <int MODE>
 static int launch_ring_mode(const ConvArgs& a, hipStream_t st) {
@@ -249,9 +254,10 @@ static int launch_ring_mode(const ConvArgs& a, hipStream_t st) {
             return STABNET_ERR_LAUNCH;
         }
         g_ring_wgs = env_int("STABNET_CONV_RING_WGS_PER_CU", 3) * cus;
+        g_ring_cus = cus;
     }
     const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64) * a.splitk;
-    const int grid = (int)std::min<long>(ntiles, g_ring_wgs);
+    const int grid = (int)std::min<long>(ntiles, ring_grid_cap());
     if (g_bf16_operands) conv_ring_f32_kernel<MODE, 1><<<grid, 256, 0, st>>>(a);
     else conv_ring_f32_kernel<MODE, 0><<<grid, 256, 0, st>>>(a);
     SN_LAUNCH_CHECK("conv_ring_f32_kernel");
@@ -315,7 +321,7 @@ static int launch_ring_kg(const ConvArgs& a, int kg, hipStream_t st) {
         return STABNET_ERR_LAUNCH;
     }
     const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64);
-    const int grid = (int)std::min<long>(ntiles, cus);                 // 144 (102) KiB of LDS: one workgroup per CU
+    const int grid = (int)std::min<long>(ntiles, usable_cus(cus));     // 144 (102) KiB of LDS: one workgroup per CU
     if (kg == 2) conv_ring_f32_kernel<0, 0, 2, 1><<<grid, 512, 0, st>>>(a);
     else if (a.pad == 0) conv_ring_f32_kernel<0, 0, 3><<<grid, 768, 0, st>>>(a);
     else conv_ring_f32_kernel<1, 0, 3><<<grid, 768, 0, st>>>(a);
@@ -343,10 +349,11 @@ static int launch_ring_pro(ConvArgs a, long delta, hipStream_t st) {
             return STABNET_ERR_LAUNCH;
         }
         g_ring_wgs = env_int("STABNET_CONV_RING_WGS_PER_CU", 3) * cus;
+        g_ring_cus = cus;
     }
     a.out_floor = reinterpret_cast<const float*>((size_t)delta);      // the kernel's pair distance (not a pointer: see conv_ring_kernel.h PRO)
     const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64) * a.splitk;
-    const int grid = (int)std::min<long>(ntiles, g_ring_wgs);
+    const int grid = (int)std::min<long>(ntiles, ring_grid_cap());
     conv_ring_f32_kernel<0, 0, 1, 1><<<grid, 256, 0, st>>>(a);
     SN_LAUNCH_CHECK("conv_ring_f32_kernel<PRO>");
     return STABNET_OK;
@@ -508,9 +515,9 @@ int conv_b2b_launch(const ConvArgs& c2, const ConvArgs& c3, hipStream_t st, Prof
     const bool rec = prof != nullptr && prof->begin(st);
     if (c2.Cout == 64) {
         static const int wgs = env_int("STABNET_CONV_B2B_WGS_PER_CU", 2);     // 80 KB of LDS each
-        conv_b2b_f32_kernel<2><<<std::min(tiles_m, wgs * cus), 256, 0, st>>>(P);
+        conv_b2b_f32_kernel<2><<<std::min(tiles_m, wgs * usable_cus(cus)), 256, 0, st>>>(P);
     } else {
-        conv_b2b_f32_kernel<4><<<std::min(tiles_m, cus), 512, 0, st>>>(P);    // 136 KB of LDS
+        conv_b2b_f32_kernel<4><<<std::min(tiles_m, usable_cus(cus)), 512, 0, st>>>(P);    // 136 KB of LDS
     }
     if (rec) prof->end(st, PK_KERNEL_CONV_B2B + (c2.Cout == 128 ? 1 : 0),
                        2.0 * c2.M * ((double)c2.K * c2.Cout + (double)c3.K * c3.Cout),
@@ -551,6 +558,12 @@ extern "C" {
 
 /* Tuning hook: force the tile (0 = 128x128, 1 = 128x64, 2 = 64x64) and split-K of every subsequent convolution;
  * tile < 0 restores the built-in choice.  Not thread-safe; used by tools/autotune.py only. */
+int stabnet_conv_reserve_cus(int reserved) {
+    const int prev = g_reserved_cus;
+    g_reserved_cus = reserved < 0 ? 0 : reserved;
+    return prev;
+}
+
 void stabnet_conv_tuning_override(int tile, int splitk) {
     g_force_tile = tile < 0 ? -1 : tile;
     g_force_split = splitk;

@@ -50,7 +50,38 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(const probe_f32x4* __re
     if (i < n4) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
+// A stand-in for a collective's kernel on a one-GPU box: FEW long-lived workgroups (RCCL runs one per channel)
+// that stream dst[i] += src[i] over a bucket with a grid-stride loop, each holding `lds` bytes of LDS so that it competes for the
+// same CU resources a real collective kernel would.  Launched on a second stream beside the backward it answers two questions a
+// one-rank RCCL group cannot (a sum over one rank moves nothing): does a small kernel get CU slots while the persistent conv
+// kernels own every CU, and what does the step pay for it.
+__global__ __launch_bounds__(256) void probe_comm_proxy_kernel(const probe_f32x4* __restrict__ src, probe_f32x4* __restrict__ dst, long n4,
+                                                               unsigned long long* __restrict__ stamps) {
+    extern __shared__ float proxy_lds[];
+    if (threadIdx.x == 0 && stamps != nullptr) stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    float keep = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const probe_f32x4 a = src[i], b = dst[i];
+        dst[i] = a + b;
+        keep += a[0];
+    }
+    if (keep == 123.456f) proxy_lds[threadIdx.x] = keep;            // (keeps the LDS allocation alive)
+    if (threadIdx.x == 0 && stamps != nullptr) stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+}
+
 extern "C" {
+
+/* dst[i] += src[i] by `workgroups` long-lived workgroups of 256 threads holding lds_bytes of LDS each (stand-in for a collective's
+ * kernel; bytes moved = 12 * n_floats).  stamps (optional, device, 2 words per workgroup): 100 MHz ticks at entry and exit. */
+int stabnet_probe_comm_proxy(const float* src, float* dst, long n_floats, int workgroups, int lds_bytes, unsigned long long* stamps,
+                             void* stream) {
+    SN_REQUIRE(src && dst && n_floats > 0 && (n_floats & 3) == 0 && workgroups > 0 && lds_bytes >= 0 && lds_bytes <= 64 * 1024,
+               "probe_comm_proxy: bad arguments");
+    probe_comm_proxy_kernel<<<workgroups, 256, (size_t)lds_bytes, (hipStream_t)stream>>>(reinterpret_cast<const probe_f32x4*>(src),
+                                                                                      reinterpret_cast<probe_f32x4*>(dst), n_floats / 4, stamps);
+    SN_LAUNCH_CHECK("probe_comm_proxy_kernel");
+    return STABNET_OK;
+}
 
 /* out: blocks*256 floats.  FLOPs executed = stabnet_probe_mfma_f32_flops(blocks, iters).  stamps (optional, device, 2 words per
  * block): {shader cycles, 100 MHz ticks} spent inside the MFMA loop by wave 0 of each block -> the clock held under load. */

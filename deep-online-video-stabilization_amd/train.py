@@ -10,6 +10,8 @@ Every tensor op is a C-ABI kernel; torch allocates, holds pointers, owns the str
 reproducible bit for bit (no order-dependent float atomics anywhere on the path)."""
 from __future__ import annotations
 
+import os
+
 import ctypes
 
 import numpy as np
@@ -82,6 +84,11 @@ class Trainer:
         self.pg = process_group
         self.world = world_size
         self.comm = world_size > 1 or (force_comm and process_group is not None)
+        if self.comm and os.environ.get("STABNET_COMM_RESERVED_CUS"):
+            # CUs the persistent conv grids leave free for the collective's kernels.  Default: none -- measured with a stand-in
+            # kernel (tools/comm_proxy.py) a 32-workgroup kernel on a second stream gets its CU slots within
+            # 1.5 us beside the backward without any reservation, and reserving 16 / 32 CUs costs the step 1.1 / 2.6 %.
+            _lib.lib().stabnet_conv_reserve_cus(int(os.environ["STABNET_COMM_RESERVED_CUS"]))
         self.comm_stream = torch.cuda.Stream(device=dev) if self.comm else None
         self.last = None
         self.prof = None                                        # deploy.Profiler: per-launch HIP events (bench only)

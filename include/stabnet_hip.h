@@ -182,6 +182,16 @@ int stabnet_probe_mfma_f32(float* out /* blocks*256 floats */, int blocks, int i
                            void* stream);
 double stabnet_probe_mfma_f32_flops(int blocks, int iters);
 int stabnet_probe_hbm_copy(const float* src, float* dst, long n_floats, void* stream);
+/* Stand-in for a collective's kernel on a one-GPU box: dst[i] += src[i] by `workgroups` long-lived
+ * workgroups of 256 threads holding lds_bytes (<= 64 KiB) of LDS each; stamps (optional, device, 2 words per workgroup):
+ * 100 MHz ticks at its entry and exit.  Not on the product path. */
+int stabnet_probe_comm_proxy(const float* src, float* dst, long n_floats, int workgroups, int lds_bytes, unsigned long long* stamps,
+                             void* stream);
+/* CUs the persistent convolution kernels leave free (0 = none, the default): their grids are sized for (CUs - reserved) x
+ * workgroups-per-CU, so that a collective's kernel on a communication stream finds CU slots without waiting for a kernel
+ * boundary.  A process-wide setting read at launch time (train.Trainer sets it from STABNET_COMM_RESERVED_CUS when it has a
+ * process group); returns the previous value. */
+int stabnet_conv_reserve_cus(int reserved);
 
 /* ---- training: backward of the warp / sampler and the loss kernels ---------------------------------------
  * These replace what TF autodiff generates for `opt.minimize(total_loss)` (train_bundle_nobm.py:160) over the ops
