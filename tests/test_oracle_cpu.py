@@ -185,9 +185,23 @@ def test_cv_restatement_known_answers():
     mx = np.tile(np.arange(W, dtype=np.float32)[None], (H, 1))
     my = np.tile(np.arange(H, dtype=np.float32)[:, None], (1, W))
     assert np.array_equal(O.cv_remap_linear_u8(img, mx, my), img)
-    half = O.cv_remap_linear_u8(img, mx + 0.5, my)                       # half-pixel shift = mean of neighbours
-    want = np.rint((img[:, :-1].astype(np.float32) + img[:, 1:].astype(np.float32)) / 2)
-    assert np.array_equal(half[:, :-1], want.astype(np.uint8))
+    half = O.cv_remap_linear_u8(img, mx + 0.5, my)                       # half-pixel shift = mean of neighbours ...
+    a, b = img[:, :-1].astype(np.int64), img[:, 1:].astype(np.int64)
+    assert np.array_equal(half[:, :-1], ((a + b + 1) >> 1).astype(np.uint8))   # ... rounded half UP: (16384 a + 16384 b + 16384) >> 15
+    assert np.array_equal(half[:, -1], (img[:, -1].astype(np.int64) + 1) >> 1)  # the right tap of the last column is the border value 0
+    # OpenCV's fixed-point weight table (initInterTab2D): sums to 32768 everywhere, exact multiples of 32 except entry (0, 0), whose
+    # 1.0 saturates to 32767 and whose repair lands on tap [1][1]
+    tab = O.cv_bilinear_tab_i()
+    assert tab.shape == (1024, 4) and (tab.sum(1) == 32768).all() and tab.min() >= 0
+    assert tab[0].tolist() == [32767, 0, 0, 1] and tab[1].tolist() == [31744, 1024, 0, 0] and tab[32 * 16 + 16].tolist() == [8192] * 4
+    assert (tab[1:] % 32 == 0).all()
+    # a quarter-pixel shift down-right: weights 9/16, 3/16, 3/16, 1/16 exactly
+    q = O.cv_remap_linear_u8(img, mx + 0.25, my + 0.25)[:-1, :-1].astype(np.int64)
+    p00, p01, p10, p11 = (img[:-1, :-1].astype(np.int64), img[:-1, 1:].astype(np.int64), img[1:, :-1].astype(np.int64), img[1:, 1:].astype(np.int64))
+    assert np.array_equal(q, (18432 * p00 + 6144 * p01 + 6144 * p10 + 2048 * p11 + 16384) >> 15)
+    # out-of-frame and non-finite coordinates read the border
+    far = O.cv_remap_linear_u8(img, np.full_like(mx, 1e30), np.full_like(my, np.nan))
+    assert not far.any()
     # resize: a constant map stays constant, a shrink by 4 of a ramp samples its centre of mass
     assert np.all(O.cv_resize_linear_f32(np.full((8, 8), 3.0, np.float32), 2, 2) == 3.0)
     ramp = np.tile(np.arange(8, dtype=np.float32)[None], (8, 1))
