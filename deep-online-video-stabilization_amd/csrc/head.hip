@@ -71,13 +71,35 @@ __global__ __launch_bounds__(256) void fc_gap_kernel(const float* __restrict__ p
 // output_layer (no activation) + mesh.  Workgroup b: sample n = b / bps, cells 4 (b % bps) + wave, bps = ceil(cells / 4).
 // Each wave takes the rows wave, wave + 4, ... of the layer: all their weight loads first, all the dot products, then all the
 // wave reductions together (one row at a time, the 6 dependent cross-lane steps of a reduction were the kernel's critical path).
+// Warm-up of the sampler's gather (round 4): this launch is a latency chain on 4 workgroups while the other 252 CUs idle, and the
+// launch behind it -- the sampler -- gathers from a frame that was last touched 1.8 ms and ~300 MB of traffic ago (cold in L2
+// and mostly in the Infinity Cache).  The workgroups >= mesh_blocks do nothing but READ that frame: block ids are dealt round-robin
+// over the 8 XCDs and the sampler gives the workgroups of XCD x the x-th eighth of the rows (sn_xcd_band), so the prefetching
+// workgroups of XCD x read band x (+ a halo of rows for the warp's displacement) -- the lines land in the L2 the gathers will hit.
+struct HeadPrefetch { const float* src; int N, H, W, mesh_blocks; };
+__device__ __forceinline__ void head_prefetch_rows(const HeadPrefetch& pf, float* sink) {
+    const int id = (int)blockIdx.x, P = (int)gridDim.x - pf.mesh_blocks;      // P % 8 == 0 (launcher)
+    const int xcd = id & 7, rank = (id - pf.mesh_blocks) >> 3, per_xcd = P >> 3;
+    constexpr int HALO = 24;
+    const int r0 = max(0, xcd * pf.H / 8 - HALO), r1 = min(pf.H, (xcd + 1) * pf.H / 8 + HALO);
+    const long band4 = (long)(r1 - r0) * pf.W / 4;                            // float4s of the band (W % 4 == 0: launcher)
+    const long lo = band4 * rank / per_xcd, hi = band4 * (rank + 1) / per_xcd;
+    float acc = 0.f;
+    for (int n = 0; n < pf.N; ++n) {
+        const float4* p = reinterpret_cast<const float4*>(pf.src + ((size_t)n * pf.H + r0) * pf.W);
+        for (long i = lo + threadIdx.x; i < hi; i += 256) { const float4 v = p[i]; acc += v.x + v.w; }
+    }
+    if (acc == 1.2345e38f) *sink = acc;                                       // (never: keeps the loads)
+}
+
 template <int K /* 512 */>
 __global__ __launch_bounds__(256) void theta_mesh_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                          int n_theta, float* __restrict__ theta, int gh, int gw, float lim,
-                                                         float* __restrict__ Hs, int* __restrict__ head_adv, int depth) {
+                                                         float* __restrict__ Hs, int* __restrict__ head_adv, int depth, const HeadPrefetch pf) {
     constexpr int RMAX = 16;                                             // rows per wave: n_theta <= 64
     __shared__ __attribute__((aligned(16))) float xs[K];
     __shared__ float th[64];
+    if ((int)blockIdx.x >= pf.mesh_blocks) { head_prefetch_rows(pf, th); return; }   // workgroup-uniform
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cells = gh * gw, bps = (cells + 3) / 4;
     const int n = blockIdx.x / bps, cg = blockIdx.x - n * bps;
@@ -147,10 +169,14 @@ int launch_gap_fc1(const float* x, const float* scale, const float* shift, int N
 }
 
 int launch_theta_mesh(const float* x, const float* w, const float* b, int N, int n_theta, float* theta, int gh, int gw, float lim,
-                      float* Hs, int* head_adv, int depth, hipStream_t st) {
+                      float* Hs, int* head_adv, int depth, hipStream_t st, const float* prefetch_src, int pf_H, int pf_W) {
     SN_REQUIRE(n_theta <= 64 && gh * gw <= 64, "theta_mesh: bad shape");
     const int bps = Hs != nullptr ? (gh * gw + 3) / 4 : 1;
-    theta_mesh_kernel<512><<<N * bps, 256, 0, st>>>(x, w, b, n_theta, theta, Hs != nullptr ? gh : 1, Hs != nullptr ? gw : 1, lim, Hs, head_adv, depth);
+    static const int pf_blocks = []() { const char* v = getenv("STABNET_HEAD_PREFETCH_BLOCKS"); return v ? atoi(v) / 8 * 8 : 256; }();
+    const bool pf_on = prefetch_src != nullptr && pf_blocks > 0 && pf_W % 4 == 0 && pf_H >= 8 && ((size_t)prefetch_src & 15) == 0;
+    const HeadPrefetch pf{prefetch_src, N, pf_H, pf_W, N * bps};
+    theta_mesh_kernel<512><<<N * bps + (pf_on ? pf_blocks : 0), 256, 0, st>>>(x, w, b, n_theta, theta, Hs != nullptr ? gh : 1, Hs != nullptr ? gw : 1,
+                                                                             lim, Hs, head_adv, depth, pf);
     SN_LAUNCH_CHECK("theta_mesh_kernel");
     return STABNET_OK;
 }

@@ -25,4 +25,4 @@ int head_gap_chunks(int N, int HW);
 int launch_gap_fc1(const float* x, const float* scale, const float* shift, int N, int HW, int C, float* partial, float* gap_out,
                    const float* w, const float* b, float* y, int Nout, hipStream_t st);
 int launch_theta_mesh(const float* x, const float* w, const float* b, int N, int n_theta, float* theta, int gh, int gw, float lim,
-                      float* Hs, int* head_adv, int depth, hipStream_t st);
+                      float* Hs, int* head_adv, int depth, hipStream_t st, const float* prefetch_src = nullptr, int pf_H = 0, int pf_W = 0);

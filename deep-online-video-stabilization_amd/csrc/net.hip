@@ -505,7 +505,7 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
 
 // What the online loop hangs behind the regressor's head: get_4_pts + get_Hs (+ the ring-head advance).  With the shortened
 // head (head.hip) they ride in the output layer's launch; `done` tells the caller whether run_forward did them.
-struct MeshTail { int gh, gw; float lim; float* Hs; int* head_adv; int depth; bool done; };
+struct MeshTail { int gh, gw; float lim; float* Hs; int* head_adv; int depth; bool done; const float* prefetch_src = nullptr; /* the frame the sampler behind the mesh gathers from */ };
 
 static int run_forward(const Net* net, const float* params, const float* fold, const float* x, float* theta,
                        float* ws, hipStream_t st, Prof* prof = nullptr, bool skip_pad = false, MeshTail* mesh = nullptr) {
@@ -546,6 +546,11 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
                     a.relu_out = 0;
                 }
                 a.partial = splitk;
+                {   // experiment switch (tools/layer_table.py): every convolution launched twice, the SECOND one timed -- its weights
+                    // (and output lines) are warm: the upper bound of what prefetching a layer's weights could buy
+                    static const int twice = []() { const char* v = getenv("STABNET_DEBUG_CONV_TWICE"); return v ? atoi(v) : 0; }();
+                    if (twice && (rc = conv_launch(a, st, nullptr, net->bf16_operands)) != 0) break;
+                }
                 rc = conv_launch(a, st, prof, net->bf16_operands);
                 break;
             }
@@ -600,7 +605,8 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
         const bool rec = prof != nullptr && prof->begin(st);
         const int rc = launch_theta_mesh(ws + net->t_fc[2].off, params + net->fc_w[3], params + net->fc_b[3], net->N, net->n_theta, theta,
                                          mesh ? mesh->gh : 1, mesh ? mesh->gw : 1, mesh ? mesh->lim : 0.f, mesh ? mesh->Hs : nullptr,
-                                         mesh ? mesh->head_adv : nullptr, mesh ? mesh->depth : 1, st);
+                                         mesh ? mesh->head_adv : nullptr, mesh ? mesh->depth : 1, st,
+                                         mesh ? mesh->prefetch_src : nullptr, net->H, net->W);
         if (rec) prof->end(st, PK_KERNEL_HEAD, 2.0 * net->N * 512 * net->n_theta, 4.0 * 512 * net->n_theta);
         if (rc) return rc;
         if (mesh) mesh->done = true;
@@ -904,6 +910,7 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
         // fused push: whoever computes the mesh also advances the ring head (nothing between the stack assembly and the
         // sampler reads it): the fused head's last phase, or the mesh kernel
         MeshTail mt{grid_h, grid_w, 1.0f / do_crop_rate, Hs, fused_push ? head : nullptr, depth, false};
+        mt.prefetch_src = cur;                               // warmed into the sampler's L2s while the head's latency chain runs
         rc = run_forward(net, params, fold, nullptr, theta, ws, st, prof, true, &mt);
         if (rc) return rc;
         if (!mt.done) {
