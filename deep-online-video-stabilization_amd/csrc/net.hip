@@ -546,11 +546,6 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
                     a.relu_out = 0;
                 }
                 a.partial = splitk;
-                {   // experiment switch (tools/layer_table.py): every convolution launched twice, the SECOND one timed -- its weights
-                    // (and output lines) are warm: the upper bound of what prefetching a layer's weights could buy
-                    static const int twice = []() { const char* v = getenv("STABNET_DEBUG_CONV_TWICE"); return v ? atoi(v) : 0; }();
-                    if (twice && (rc = conv_launch(a, st, nullptr, net->bf16_operands)) != 0) break;
-                }
                 rc = conv_launch(a, st, prof, net->bf16_operands);
                 break;
             }
