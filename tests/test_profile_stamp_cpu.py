@@ -80,8 +80,8 @@ def test_bench_uses_the_stamped_profile(tmp_path, monkeypatch):
     bench.annotate_roofline(roof, got, note, prof)
     assert roof["frac"] == pytest.approx(2.2624e9 / 28e-6 / 1e12 / 157.3) and roof["frac_rocprofv3"] == pytest.approx(roof["frac"])
     assert roof["hip_event_offset_us_subtracted"] == pytest.approx(2.5) and "calibrated" in roof["hip_event_offset_source"]
-    assert roof["traffic"] == pytest.approx(8192.0 * 1024.0) and roof["algorithmic_bytes_per_launch"] == pytest.approx(38.5e6)
-    assert roof["traffic_over_algorithmic"] == pytest.approx(8192.0 * 1024.0 / 38.5e6) and "Infinity Cache" in roof["traffic_counts"]
+    assert roof["traffic"] == pytest.approx(8000.0 * 1024.0) and roof["algorithmic_bytes_per_launch"] == pytest.approx(38.5e6)
+    assert roof["traffic_over_algorithmic"] == pytest.approx(8000.0 * 1024.0 / 38.5e6) and "Infinity Cache" in roof["traffic_counts"]
     # without a profile: the default offset is named as such
     prof2 = types.SimpleNamespace(offsets_us={}, idle_pair_ms=4.6e-3, offset_ms=lambda n: 2.3e-3)
     roof2, _ = bench.roofline_from_records(recs, 1)
