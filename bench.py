@@ -440,10 +440,23 @@ def main():
         torch.cuda.set_device(dev_index)
         # "nccl" = RCCL over xGMI.  STABNET_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks.
         backend = os.environ.get("STABNET_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
+        # librccl prints a five-line version banner on STDOUT when its first communicator is created; stdout carries exactly ONE
+        # JSON line (the driver parses it): fd 1 points at stderr while the group and its communicator come up
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+                t0_ = torch.zeros(1, device=torch.device("cuda", dev_index))
+                dist.all_reduce(t0_)                          # (the communicator is created here at the latest)
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(backend)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         world = dist.get_world_size()                     # what the process group really has; this is what n_gpus reports
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
