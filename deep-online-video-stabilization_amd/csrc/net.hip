@@ -376,8 +376,8 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             // Inference plan, block 1 / block 2 units with enough 64-pixel tiles to fill the chip: conv2 and conv3 as ONE launch
             // (conv_b2b_kernel.h): the activated conv2 tile stays in LDS, the low-K conv3 launch and the round trip of its input go.
             // OFF by default (STABNET_CONV_B2B_PLAN=1 turns it on): measured in the 720p frame (same box, same build) every choice
-            // of units loses to the two launches -- all six eligible units 541.5 against 554.3 frames/s, the three 225-tile
-            // units of block 1 / block 2 545.5, block 1's strided unit alone 551.6 (the fused
+            // of units loses to the two launches -- all six eligible units 549.0 against 556.4 frames/s, the three 225-tile
+            // units of block 1 / block 2 550.5, block 1's strided unit alone 555.3 (the fused
             // launch has no more matrix throughput per step than the two kernels, 80 / 136 KB of LDS leave two / one workgroup per
             // CU, and the 1x1 phase costs its 8 K-steps plus four epilogues that nothing overlaps).  The window [min_tiles,
             // max_tiles] and the d_b mask (bit 0: 64, bit 1: 128) select units when the plan switch is on.
