@@ -11,21 +11,55 @@ __global__ __launch_bounds__(256) void black_accumulate_kernel(const float* __re
     if (i < n) all_black[i] += (int)rintf(black[i]);                       // np.round(black).astype(int64), :291
 }
 
-// S[(H+1) x (W+1)], S[y+1][x+1] = sum all_black[0..y][0..x].  Row pass: one thread per row; column pass: one per column.
-__global__ __launch_bounds__(256) void integral_rows_kernel(const int* __restrict__ a, int H, int W, long long* __restrict__ S) {
-    const int y = blockIdx.x * 256 + threadIdx.x;
-    if (y > H) return;
-    long long* row = S + (size_t)y * (W + 1);
-    row[0] = 0;
-    if (y == 0) { for (int x = 1; x <= W; ++x) row[x] = 0; return; }
-    long long s = 0;
-    for (int x = 0; x < W; ++x) { s += a[(size_t)(y - 1) * W + x]; row[x + 1] = s; }
+// S[(H+1) x (W+1)], S[y+1][x+1] = sum all_black[0..y][0..x] (int64: integer sums, any order gives the same bits).
+// Row pass: one WAVE per row -- 64 consecutive elements per trip (coalesced), inclusive scan across the lanes by shuffles, the
+// running total carried in a register.  (Round 4: the first form, one THREAD per row walking W dependent loads, took 456 us at
+// 720p; this one is bandwidth-shaped.)
+__device__ __forceinline__ long long sn_shfl_up_i64(long long v, int d) {
+    const int lo = __shfl_up((int)(v & 0xffffffffll), d, 64), hi = __shfl_up((int)(v >> 32), d, 64);
+    return ((long long)hi << 32) | (unsigned int)lo;
 }
+__global__ __launch_bounds__(256) void integral_rows_kernel(const int* __restrict__ a, int H, int W, long long* __restrict__ S) {
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (y > H) return;                                                       // wave-uniform
+    long long* row = S + (size_t)y * (W + 1);
+    if (y == 0) { for (int x = lane; x <= W; x += 64) row[x] = 0; return; }
+    if (lane == 0) row[0] = 0;
+    const int* src = a + (size_t)(y - 1) * W;
+    long long carry = 0;
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        long long v = x < W ? (long long)src[x] : 0ll;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long u = sn_shfl_up_i64(v, d);
+            if (lane >= d) v += u;
+        }
+        v += carry;
+        if (x < W) row[x + 1] = v;
+        carry = ((long long)__shfl((int)(v >> 32), 63, 64) << 32) | (unsigned int)__shfl((int)(v & 0xffffffffll), 63, 64);   // lane 63's total
+    }
+}
+// Column pass: a workgroup owns 16 columns, its 16 row groups sum their rows independently (loads in flight, no chain across the
+// whole column), the group offsets go through LDS, then every group rewrites its rows as running totals.  (First form: one
+// thread per column, H dependent load -> add -> store steps: 187 us at 720p.)
 __global__ __launch_bounds__(256) void integral_cols_kernel(int H, int W, long long* __restrict__ S) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x > W) return;
+    __shared__ long long part[16][17];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int x = blockIdx.x * 16 + c;
+    const int rows = (H + 15) / 16;                                          // rows per group (rows 1 .. H of S)
+    const int y0 = 1 + g * rows, y1 = min(H + 1, y0 + rows);
     long long s = 0;
-    for (int y = 1; y <= H; ++y) { s += S[(size_t)y * (W + 1) + x]; S[(size_t)y * (W + 1) + x] = s; }
+    if (x <= W)
+        for (int y = y0; y < y1; ++y) s += S[(size_t)y * (W + 1) + x];
+    part[g][c] = s;
+    __syncthreads();
+    long long off = 0;
+    for (int k = 0; k < g; ++k) off += part[k][c];
+    if (x <= W) {
+        long long run = off;
+        for (int y = y0; y < y1; ++y) { run += S[(size_t)y * (W + 1) + x]; S[(size_t)y * (W + 1) + x] = run; }
+    }
 }
 
 // key = area << 32 | (0xFFFFFFFF - order): larger area first, then the EARLIER candidate in the reference's loop order.
@@ -115,9 +149,9 @@ int stabnet_crop_search(const int* all_black, int H, int W, int step, int* ans5,
         stabnet_set_error("crop_search: memset failed");
         return STABNET_ERR_LAUNCH;
     }
-    integral_rows_kernel<<<cdiv(H + 1, 256), 256, 0, st>>>(all_black, H, W, S);
+    integral_rows_kernel<<<cdiv(H + 1, 4), 256, 0, st>>>(all_black, H, W, S);          // one wave per row of S
     SN_LAUNCH_CHECK("integral_rows_kernel");
-    integral_cols_kernel<<<cdiv(W + 1, 256), 256, 0, st>>>(H, W, S);
+    integral_cols_kernel<<<cdiv(W + 1, 16), 256, 0, st>>>(H, W, S);         // 16 columns x 16 row groups per workgroup
     SN_LAUNCH_CHECK("integral_cols_kernel");
     crop_search_kernel<<<ni * nj, 256, 0, st>>>(all_black, S, H, W, step, nj, key, rects);
     SN_LAUNCH_CHECK("crop_search_kernel");

@@ -75,6 +75,85 @@ __global__ __launch_bounds__(256) void remap_color_kernel(const unsigned char* _
     }
 }
 
+// Four consecutive pixels per thread (C == 3, W % 4 == 0: the colour frames of the path).  The byte traffic of the one-pixel kernel
+// above -- 12 one-byte gathers and 3 one-byte stores per pixel -- becomes 4-byte traffic: the two taps of a row are 6 CONTIGUOUS bytes
+// (BGR BGR), fetched as the three aligned dwords that cover them and funnel-shifted into place; the 12 output bytes of the four pixels
+// leave as three 4-byte stores of one thread (12 contiguous bytes).  Same integer arithmetic, same results (tests/test_remap_gpu.py: exact against the oracle).
+__device__ __forceinline__ unsigned long long remap_load6(const unsigned char* __restrict__ im, long b, long total) {
+    // bytes b .. b+5 of the frame in the low 48 bits (b >= 0, b + 3 <= total: at least the first tap is in the buffer): the three
+    // aligned dwords that cover them (b may sit at byte 3 of its dword), funnel-shifted; the last pixels of the frame, whose third
+    // dword would lie past the buffer, take the bytes one by one
+    const long al = b & ~3L;
+    const int sh = 8 * (int)(b & 3);
+    if (al + 12 <= total) {
+        const unsigned* p = reinterpret_cast<const unsigned*>(im + al);
+        const unsigned d0 = p[0], d1 = p[1], d2 = p[2];
+        const unsigned lo = (unsigned)(((((unsigned long long)d1) << 32) | d0) >> sh), hi = (unsigned)(((((unsigned long long)d2) << 32) | d1) >> sh);
+        return (((unsigned long long)hi) << 32) | lo;
+    }
+    unsigned long long r = 0ull;
+    for (int k = 0; k < 6; ++k)
+        if (b + k < total) r |= ((unsigned long long)im[b + k]) << (8 * k);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void remap_color4_kernel(const unsigned char* __restrict__ img, const float* __restrict__ small_maps,
+                                                           int H, int W, int h, int w, unsigned char* __restrict__ out,
+                                                           float* __restrict__ px_out, float* __restrict__ py_out) {
+    const int q4 = blockIdx.x * 256 + threadIdx.x;           // group of four pixels
+    const int n = blockIdx.y;
+    const int W4 = W >> 2;
+    if (q4 >= H * W4) return;
+    const int y = q4 / W4, x0 = (q4 - y * W4) * 4;
+    const Taps1D ty = cv_taps(y, h, (double)h / H);
+    const float* mx = small_maps + ((size_t)n * 2 + 0) * h * w;
+    const float* my = small_maps + ((size_t)n * 2 + 1) * h * w;
+    const unsigned char* im = img + (size_t)n * H * W * 3;
+    const long total = (long)H * W * 3;
+    unsigned ob[3] = {0u, 0u, 0u};                           // the 12 output bytes
+    float pxs[4], pys[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const Taps1D tx = cv_taps(x0 + e, w, (double)w / W);
+        const float xs = cv_resize_at(mx, w, tx, ty), ys = cv_resize_at(my, w, tx, ty);
+        const float px = (xs + 1.0f) / 2.0f * (float)W;                 // deploy_bundle.py:142-143
+        const float py = (ys + 1.0f) / 2.0f * (float)H;
+        pxs[e] = px; pys[e] = py;
+        const float qx = fminf(fmaxf(px * 32.0f, -2.0e9f), 2.0e9f), qy = fminf(fmaxf(py * 32.0f, -2.0e9f), 2.0e9f);
+        const int sx = (qx == qx) ? (int)rintf(qx) : -2000000000, sy = (qy == qy) ? (int)rintf(qy) : -2000000000;
+        const int ix = min(max(sx >> 5, -32768), 32767), iy = min(max(sy >> 5, -32768), 32767);
+        const int fx = sx & 31, fy = sy & 31;
+        int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+        if ((fx | fy) == 0) { w00 = 32767; w11 = 1; }
+        const bool vx0 = ix >= 0 && ix < W, vx1 = ix + 1 >= 0 && ix + 1 < W, vy0 = iy >= 0 && iy < H, vy1 = iy + 1 >= 0 && iy + 1 < H;
+        // rows iy and iy + 1: 6 bytes from pixel max(ix, 0) on (ix == -1: the first three bytes are tap 1)
+        unsigned long long r0 = 0ull, r1 = 0ull;
+        const int cx = max(ix, 0);
+        if ((vx0 || vx1) && vy0) r0 = remap_load6(im, ((long)iy * W + cx) * 3, total);
+        if ((vx0 || vx1) && vy1) r1 = remap_load6(im, ((long)(iy + 1) * W + cx) * 3, total);
+        if (ix < 0) { r0 <<= 24; r1 <<= 24; }                  // tap 0 out of frame on the left: what was loaded is tap 1
+        const unsigned long long m0 = vx0 ? 0xffffffull : 0ull, m1 = vx1 ? 0xffffff000000ull : 0ull;
+        r0 &= (vy0 ? (m0 | m1) : 0ull);
+        r1 &= (vy1 ? (m0 | m1) : 0ull);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int v00 = (int)((r0 >> (8 * c)) & 0xff), v01 = (int)((r0 >> (24 + 8 * c)) & 0xff);
+            const int v10 = (int)((r1 >> (8 * c)) & 0xff), v11 = (int)((r1 >> (24 + 8 * c)) & 0xff);
+            const int acc = (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15;
+            const unsigned o = (unsigned)min(max(acc, 0), 255);
+            const int byte = e * 3 + c;
+            ob[byte >> 2] |= o << (8 * (byte & 3));
+        }
+    }
+    const size_t pix = (size_t)n * H * W + (size_t)y * W + x0;
+    unsigned* op = reinterpret_cast<unsigned*>(out + pix * 3);
+    op[0] = ob[0]; op[1] = ob[1]; op[2] = ob[2];
+    if (px_out != nullptr) {
+        *reinterpret_cast<float4*>(px_out + pix) = make_float4(pxs[0], pxs[1], pxs[2], pxs[3]);
+        *reinterpret_cast<float4*>(py_out + pix) = make_float4(pys[0], pys[1], pys[2], pys[3]);
+    }
+}
+
 extern "C" {
 
 /* warpRevBundle2(img, x_map, y_map) (deploy_bundle.py:136-146): img uint8 [N,H,W,C] (BGR, C = 3), x_map, y_map [N,H,W]
@@ -89,6 +168,13 @@ int stabnet_warp_rev_bundle2(const unsigned char* img, const float* x_map, const
     hipStream_t st = (hipStream_t)stream;
     map_shrink_kernel<<<dim3(cdiv(h * w, 256), N), 256, 0, st>>>(x_map, y_map, H, W, h, w, workspace);
     SN_LAUNCH_CHECK("map_shrink_kernel");
+    static const int v4 = []() { const char* v = getenv("STABNET_REMAP_VEC4"); return v ? atoi(v) : 1; }();
+    const bool aligned = (((size_t)img | (size_t)out) & 3) == 0 && (px_out == nullptr || (((size_t)px_out | (size_t)py_out) & 15) == 0);
+    if (v4 && C == 3 && W % 4 == 0 && (long)H * W * 3 >= 8 && aligned) {
+        remap_color4_kernel<<<dim3(cdiv((long)H * W / 4, 256), N), 256, 0, st>>>(img, workspace, H, W, h, w, out, px_out, py_out);
+        SN_LAUNCH_CHECK("remap_color4_kernel");
+        return STABNET_OK;
+    }
     remap_color_kernel<<<dim3(cdiv((long)H * W, 256), N), 256, 0, st>>>(img, workspace, H, W, C, h, w, out, px_out, py_out);
     SN_LAUNCH_CHECK("remap_color_kernel");
     return STABNET_OK;

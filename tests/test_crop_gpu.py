@@ -44,3 +44,23 @@ def test_black_accumulate(cuda):
         warp.black_accumulate(torch.from_numpy(b).to(cuda), acc)
         tot += np.round(b).astype(np.int64)
     assert np.array_equal(acc.cpu().numpy(), tot)
+
+
+@pytest.mark.parametrize("H,W", [(97, 131), (288, 512), (720, 1280), (64, 65)])
+def test_integral_image_exact(cuda, H, W):
+    """The two scan kernels behind the search (one wave per row; 16 columns x 16 row groups per workgroup): the workspace starts
+    with S[(H+1) x (W+1)] int64, S[y+1][x+1] = sum of all_black[:y+1, :x+1] -- integers, so exact."""
+    from stabnet_amd import _lib
+    from stabnet_amd._tensor import ptr, stream_ptr
+    rng = np.random.default_rng(W)
+    m = rng.integers(0, 1000, (H, W)).astype(np.int32)
+    m[rng.random((H, W)) < 0.5] = 0
+    a = torch.from_numpy(m).to(cuda)
+    nbytes = _lib.lib().stabnet_crop_search_workspace_bytes(H, W, 10)
+    ws = torch.full(((nbytes + 7) // 8,), -1, dtype=torch.int64, device=cuda)
+    ans = torch.empty(5, dtype=torch.int32, device=cuda)
+    _lib.call("stabnet_crop_search", ptr(a), H, W, 10, ptr(ans), ptr(ws), ws.numel() * 8, stream_ptr(a.device), device=a.device)
+    S = ws[: (H + 1) * (W + 1)].cpu().numpy().reshape(H + 1, W + 1)
+    want = np.zeros((H + 1, W + 1), np.int64)
+    want[1:, 1:] = m.astype(np.int64).cumsum(0).cumsum(1)
+    assert np.array_equal(S, want)

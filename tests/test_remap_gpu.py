@@ -9,8 +9,9 @@ from oracle import stabnet_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("H,W", [(288, 512), (90, 130), (720, 1280)])
-def test_warp_rev_bundle2(cuda, H, W):
+@pytest.mark.parametrize("shift", [0.0, 0.45, -0.45])      # +-0.45: a fifth of the frame maps outside on the right / bottom or left / top
+@pytest.mark.parametrize("H,W", [(288, 512), (90, 130), (720, 1280), (64, 96)])   # W % 4 == 0: the four-pixels-per-thread kernel; 130: the scalar one
+def test_warp_rev_bundle2(cuda, H, W, shift):
     from stabnet_amd import warp
     from stabnet_amd.config import Config
     cfg, ocfg = Config(height=H, width=W), O.Config(height=H, width=W)
@@ -19,8 +20,13 @@ def test_warp_rev_bundle2(cuda, H, W):
     img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
     _, pts2 = O.get_4_pts(theta, ocfg)
     x_map, y_map, _ = O.maps_from_Hs(O.get_Hs(pts2, ocfg), H, W, ocfg)
+    x_map, y_map = (x_map + np.float32(shift)).astype(np.float32), (y_map + np.float32(shift)).astype(np.float32)
     want, xs, ys = O.warpRevBundle2(img, x_map[0], y_map[0])
     got, px, py = warp.warpRevBundle2(torch.from_numpy(img).to(cuda), torch.from_numpy(x_map).to(cuda),
                                       torch.from_numpy(y_map).to(cuda), return_maps=True)
     assert np.array_equal(px.cpu().numpy()[0], xs) and np.array_equal(py.cpu().numpy()[0], ys)
     assert np.array_equal(got.cpu().numpy(), want)
+    if shift:
+        assert (want == 0).all(axis=2).mean() > 0.1                       # a visible black border: the BORDER_CONSTANT taps were exercised
+    got2 = warp.warpRevBundle2(torch.from_numpy(img).to(cuda), torch.from_numpy(x_map).to(cuda), torch.from_numpy(y_map).to(cuda))
+    assert np.array_equal(got2.cpu().numpy(), want)                          # (without the optional pixel-coordinate outputs)
