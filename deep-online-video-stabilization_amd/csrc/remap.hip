@@ -154,6 +154,20 @@ __global__ __launch_bounds__(256) void remap_color4_kernel(const unsigned char* 
     }
 }
 
+// cvt_train2img (deploy_bundle.py:75): ((x + 0.5) * 255).astype(uint8), clipped to [0, 255] first (the network's grey output is a
+// bilinear blend of inputs in [-0.5, 0.5], so the clip only guards the cast).  4 pixels per thread, float4 in, one dword out.
+__global__ __launch_bounds__(256) void cvt_train2img_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    auto cv = [](float v) -> unsigned int { return (unsigned int)fminf(fmaxf((v + 0.5f) * 255.0f, 0.0f), 255.0f); };
+    if (i + 4 <= n && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        *reinterpret_cast<unsigned int*>(out + i) = cv(v.x) | (cv(v.y) << 8) | (cv(v.z) << 16) | (cv(v.w) << 24);
+    } else {
+        for (long j = i; j < n && j < i + 4; ++j) out[j] = (unsigned char)cv(x[j]);
+    }
+}
+
 extern "C" {
 
 /* warpRevBundle2(img, x_map, y_map) (deploy_bundle.py:136-146): img uint8 [N,H,W,C] (BGR, C = 3), x_map, y_map [N,H,W]
@@ -177,6 +191,14 @@ int stabnet_warp_rev_bundle2(const unsigned char* img, const float* x_map, const
     }
     remap_color_kernel<<<dim3(cdiv((long)H * W, 256), N), 256, 0, st>>>(img, workspace, H, W, C, h, w, out, px_out, py_out);
     SN_LAUNCH_CHECK("remap_color_kernel");
+    return STABNET_OK;
+}
+
+/* cvt_train2img (deploy_bundle.py:75): out[i] = uint8((x[i] + 0.5) * 255), clipped to [0, 255].  x float [n], out uint8 [n]. */
+int stabnet_cvt_train2img(const float* x, unsigned char* out, long n, void* stream) {
+    SN_REQUIRE(x && out && n > 0, "cvt_train2img: bad arguments");
+    cvt_train2img_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, (hipStream_t)stream>>>(x, out, n);
+    SN_LAUNCH_CHECK("cvt_train2img_kernel");
     return STABNET_OK;
 }
 

@@ -3,6 +3,7 @@ per stream and ONE C call per frame.  Video decode/encode and the colour remap s
 from __future__ import annotations
 
 import ctypes
+import time
 
 import numpy as np
 import torch
@@ -178,3 +179,148 @@ class StabNetStream:
             self._enqueue(prof)
         return {"output": self.out_img, "black_pix": self.black, "Hs": self.Hs, "x_map": self.x_map,
                 "y_map": self.y_map, "theta": self.theta, "frame": self.frame_fb}
+
+
+class ClipPipeline:
+    """A clip that lives in HOST memory through one StabNetStream, with upload, frame and download on three HIP streams.
+
+    The reference's loop (deploy_bundle.py:244-342) is strictly serial per frame: feed the frame, `sess.run`, `cv2.remap` the colour
+    frame, write it.  The frame itself is recurrent (frame t reads what frame t-1 fed back through the ring), so frames cannot overlap
+    each other -- but their PCIe traffic can hide behind the neighbours' compute: while frame t is on the compute stream, frame t+1
+    (grey float32 + colour uint8, 6.4 MB at 720p) is uploaded from pinned memory on a second stream and the results of frame t-1
+    (stabilised colour frame + the network's grey output, 3.7 MB) are downloaded on a third.  `slots` (>= 2) staging buffers per
+    direction; events order the three streams, the host only blocks when it reuses a slot.  Results are the same bytes the serial
+    loop produces (tests/test_pipeline_gpu.py).
+
+    run(grey, bgr=None, sink=None, maps=False): grey = sequence of host float32 [H,W] frames in the training normalisation, frame 0 seeds
+    the ring (deploy_bundle.py:206-222); bgr = matching uint8 [H,W,3] frames or None.  Per processed frame t >= 1 the host gets
+    {"t", "output" uint8 [H,W], "bgr" uint8 [H,W,3] (if bgr), "x_map"/"y_map"/"black" (if maps)}: passed to `sink` as views of pinned
+    staging memory that stay valid until the sink returns, or -- without a sink -- copied and returned as a list."""
+
+    def __init__(self, stream: StabNetStream, colour: bool = True, slots: int = 3, rate: int = 4):
+        if stream.S != 1:
+            raise _lib.StabnetError("ClipPipeline: one video stream per pipeline")
+        if slots < 2:
+            raise _lib.StabnetError("ClipPipeline: slots must be >= 2")
+        self.st, self.colour, self.slots, self.rate = stream, colour, slots, rate
+        dev = stream.reg.device
+        H, W = stream.H, stream.W
+        self.dev = dev
+        pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
+        on = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        self.h_grey = [pin((H, W), torch.float32) for _ in range(slots)]
+        self.d_grey = [on((1, H, W), torch.float32) for _ in range(slots)]
+        self.h_out = [pin((H, W), torch.uint8) for _ in range(slots)]
+        self.d_out = [on((H, W), torch.uint8) for _ in range(slots)]
+        if colour:
+            self.h_bgr = [pin((H, W, 3), torch.uint8) for _ in range(slots)]
+            self.d_bgr = [on((1, H, W, 3), torch.uint8) for _ in range(slots)]
+            self.h_warp = [pin((H, W, 3), torch.uint8) for _ in range(slots)]
+            self.d_warp = [on((1, H, W, 3), torch.uint8) for _ in range(slots)]
+            self.remap_ws = on((2 * (H // rate) * (W // rate),), torch.float32)
+        self.h_maps = None
+        self.use_graph = True
+        self._graphs = {}
+        self.s_in, self.s_run, self.s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
+        self.ev_up = [torch.cuda.Event() for _ in range(slots)]
+        self.ev_run = [torch.cuda.Event() for _ in range(slots)]
+        self.ev_down = [torch.cuda.Event() for _ in range(slots)]
+
+    def _frame(self, k: int, maps: bool):
+        """Everything frame-shaped of slot k on the current stream: staging copy, the frame, its results into the slot's buffers."""
+        st, H, W = self.st, self.st.H, self.st.W
+        st.cur.copy_(self.d_grey[k])
+        st._enqueue()
+        # cvt_train2img (deploy_bundle.py:75)
+        _lib.call("stabnet_cvt_train2img", ptr(st.out_img), ptr(self.d_out[k]), H * W, stream_ptr(self.dev), device=self.dev)
+        if self.colour:
+            _lib.call("stabnet_warp_rev_bundle2", ptr(self.d_bgr[k]), ptr(st.x_map), ptr(st.y_map), 1, H, W, 3, self.rate,
+                      ptr(self.d_warp[k]), ptr(self.remap_ws), 0, 0, stream_ptr(self.dev), device=self.dev)
+        if maps:
+            self.d_maps[0][k].copy_(st.x_map.view(H, W)); self.d_maps[1][k].copy_(st.y_map.view(H, W))
+            self.d_maps[2][k].copy_(st.black.view(H, W))
+
+    def _capture(self, k: int, maps: bool):
+        try:
+            with torch.cuda.device(self.dev):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._frame(k, maps)
+            return g
+        except Exception as e:                       # capture unsupported on this runtime: stay eager, say so once
+            import sys
+            print("ClipPipeline: hipGraph capture failed (%s); continuing without graphs" % e, file=sys.stderr)
+            self.use_graph = False
+            return None
+
+    def _result(self, slot: int, t: int, maps: bool):
+        r = {"t": t, "output": self.h_out[slot].numpy()}
+        if self.colour:
+            r["bgr"] = self.h_warp[slot].numpy()
+        if maps:
+            r["x_map"], r["y_map"], r["black"] = (m[slot].numpy() for m in self.h_maps)
+        return r
+
+    def run(self, grey, bgr=None, sink=None, maps: bool = False):
+        st, H, W, K = self.st, self.st.H, self.st.W, self.slots
+        if self.colour and bgr is None:
+            raise _lib.StabnetError("ClipPipeline.run: this pipeline was built with colour=True, bgr frames are required")
+        if maps and self.h_maps is None:
+            self.h_maps = tuple([torch.empty((H, W), dtype=dt, pin_memory=True) for _ in range(K)]
+                                for dt in (torch.float32, torch.float32, torch.uint8))
+            self.d_maps = tuple([torch.empty((H, W), dtype=dt, device=self.dev) for _ in range(K)]
+                                for dt in (torch.float32, torch.float32, torch.uint8))
+        results = []
+        emit = sink if sink is not None else (lambda r: results.append({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r.items()}))
+        n = len(grey)
+        self.host_wait_s = 0.0                                # time the host spent blocked on a slot: ~0 means the HOST is the bound
+        torch.cuda.synchronize(self.dev)
+        with torch.cuda.stream(self.s_run):
+            first = torch.from_numpy(np.ascontiguousarray(grey[0], dtype=np.float32)).to(self.dev)
+            st.start(first[None])
+        pending = [None] * K                                  # frame number whose results sit in (or are on their way to) slot k
+        for t in range(1, n):
+            k = t % K
+            if pending[k] is not None:                        # slot reuse: its download must have landed; hand the frame over
+                w0 = time.perf_counter()
+                self.ev_down[k].synchronize()
+                self.host_wait_s += time.perf_counter() - w0
+                emit(self._result(k, pending[k], maps))
+                pending[k] = None
+            self.h_grey[k].numpy()[...] = grey[t]
+            if self.colour:
+                self.h_bgr[k].numpy()[...] = bgr[t]
+            with torch.cuda.stream(self.s_in):
+                self.d_grey[k].copy_(self.h_grey[k].view(1, H, W), non_blocking=True)
+                if self.colour:
+                    self.d_bgr[k].copy_(self.h_bgr[k].view(1, H, W, 3), non_blocking=True)
+                self.ev_up[k].record(self.s_in)
+            with torch.cuda.stream(self.s_run):
+                self.s_run.wait_event(self.ev_up[k])
+                key = (k, maps, ptr(st.all_black))
+                g = self._graphs.get(key)
+                if g is not None:
+                    g.replay()
+                else:
+                    # first use of this slot: the frame runs eagerly, then the same launches are RECORDED (nothing executes during a
+                    # capture) into the slot's own hipGraph: in steady state a frame is one graph launch per slot, no eager kernels
+                    self._frame(k, maps)
+                    if self.use_graph:
+                        self._graphs[key] = self._capture(k, maps)
+                self.ev_run[k].record(self.s_run)
+            with torch.cuda.stream(self.s_out):
+                self.s_out.wait_event(self.ev_run[k])
+                self.h_out[k].copy_(self.d_out[k], non_blocking=True)
+                if self.colour:
+                    self.h_warp[k].copy_(self.d_warp[k].view(H, W, 3), non_blocking=True)
+                if maps:
+                    for h, d in zip(self.h_maps, self.d_maps):
+                        h[k].copy_(d[k], non_blocking=True)
+                self.ev_down[k].record(self.s_out)
+            pending[k] = t                                    # (the slot's next upload follows the host's wait on ev_down[k])
+        order = sorted((p, k) for k, p in enumerate(pending) if p is not None)
+        for p, k in order:
+            self.ev_down[k].synchronize()
+            emit(self._result(k, p, maps))
+        torch.cuda.synchronize(self.dev)
+        return results if sink is None else None

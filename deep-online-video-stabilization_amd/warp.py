@@ -122,6 +122,17 @@ def warpRevBundle2(img: torch.Tensor, x_map: torch.Tensor, y_map: torch.Tensor, 
     return (out, px, py) if return_maps else out
 
 
+def cvt_train2img(x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """deploy_bundle.py:75 on the device: uint8((x + 0.5) * 255), clipped; same shape as x."""
+    x = dev_f32(x, "x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    if out.dtype != torch.uint8 or not out.is_cuda or out.numel() != x.numel() or not out.is_contiguous():
+        raise _lib.StabnetError("cvt_train2img: out must be a contiguous uint8 GPU tensor of x's size")
+    _lib.call("stabnet_cvt_train2img", ptr(x), ptr(out), x.numel(), stream_ptr(x.device), device=x.device)
+    return out
+
+
 def black_accumulate(black: torch.Tensor, all_black: torch.Tensor):
     """all_black (int32, same numel) += round(black)   (deploy_bundle.py:291)."""
     black = dev_f32(black, "black")

@@ -47,6 +47,9 @@ def build_parser():
     p.add_argument('--width', type=int, default=None, help='network/warp width (reference: fixed 512)')
     p.add_argument('--synthetic', type=int, default=0, help='stabilise a synthetic shaky clip of this many frames')
     p.add_argument('--device', default='cuda:0')
+    p.add_argument('--pipeline', action='store_true',
+                   help='overlap upload / frame / download of neighbouring frames on three HIP streams (stabnet_amd.deploy.ClipPipeline); '
+                        'same output bytes, fps is then the host-to-host rate of the whole loop')
     return p
 
 
@@ -85,6 +88,70 @@ def load_weights(args, cfg):
         print('WARNING: neither %s.npz nor %s.index found' % (path, path))
     print('using seeded synthetic weights (no trained model is available offline)')
     return synthetic.make_params(cfg, seed=0, theta_scale=0.2)
+
+
+def is_colour(frame, H, W):
+    f = np.asarray(frame)
+    return f.ndim == 3 and f.shape[:2] == (H, W)
+
+
+def run_serial(stream, clip, H, W, dev, frames_out, colour_out, xmaps, ymaps, blacks):
+    """The loop as the reference writes it (deploy_bundle.py:244-342): one frame at a time, the host waiting for each step;
+    fps = frames / time inside the step, as the reference prints it (:285-289)."""
+    import torch
+    from stabnet_amd import warp
+    tot_time, length = 0.0, 0
+    first = grey_train(clip[0], H, W)
+    stream.start(torch.from_numpy(first[None]).to(dev))                       # ring = 32 x first frame, zero masks
+    for t in range(1, len(clip)):
+        cur = torch.from_numpy(grey_train(clip[t], H, W)[None]).to(dev)
+        torch.cuda.synchronize()
+        start = time.time()
+        r = stream.step(cur)                                                  # one sess.run-equivalent
+        torch.cuda.synchronize()
+        tot_time += time.time() - start
+        if is_colour(clip[t], H, W):
+            # warpRevBundle2 (deploy_bundle.py:136-146,303) on the device: colour frame remapped by the smoothed maps
+            bgr = torch.from_numpy(np.ascontiguousarray(clip[t], dtype=np.uint8)).to(dev)
+            colour_out.append(warp.warpRevBundle2(bgr, r['x_map'], r['y_map']).cpu().numpy())
+        net_output = ((r['output'][0, :, :, 0].cpu().numpy() + 0.5) * 255).clip(0, 255).astype(np.uint8)
+        frames_out.append(net_output)
+        xmaps.append(r['x_map'][0, :, :, 0].cpu().numpy()); ymaps.append(r['y_map'][0, :, :, 0].cpu().numpy())
+        blacks.append(r['black_pix'][0].cpu().numpy().astype(np.uint8))
+        length += 1
+        if length % 10 == 0:
+            print('length: ' + str(length))
+            print('fps={}'.format(length / tot_time))
+    return length, tot_time
+
+
+def run_pipelined(stream, clip, H, W, frames_out, colour_out, xmaps, ymaps, blacks):
+    """--pipeline: the same frames through stabnet_amd.deploy.ClipPipeline (upload / frame / download of neighbouring frames on
+    three HIP streams).  Same output bytes; fps = frames / wall time of the whole loop, host conversion and copies included."""
+    from stabnet_amd.deploy import ClipPipeline
+    colour = is_colour(clip[0], H, W)
+
+    class Grey:                                                               # frames converted as the pipeline asks for them
+        def __len__(self):
+            return len(clip)
+
+        def __getitem__(self, t):
+            return grey_train(clip[t], H, W)
+
+    def sink(r):                                                              # views of pinned staging memory: copy out
+        frames_out.append(r['output'].copy())
+        if colour:
+            colour_out.append(r['bgr'].copy())
+        xmaps.append(r['x_map'].copy()); ymaps.append(r['y_map'].copy()); blacks.append(r['black'].copy())
+        if len(frames_out) % 10 == 0:
+            print('length: ' + str(len(frames_out)))
+
+    start = time.time()
+    ClipPipeline(stream, colour=colour).run(Grey(), clip if colour else None, sink=sink, maps=True)
+    tot_time = time.time() - start
+    if frames_out:
+        print('fps={}'.format(len(frames_out) / tot_time))
+    return len(frames_out), tot_time
 
 
 def main():
@@ -143,27 +210,10 @@ def main():
         tot_time, length = 0.0, 0
         frames_out, xmaps, ymaps, blacks, colour_out = [], [], [], [], []
         try:
-            first = grey_train(clip[0], H, W)
-            stream.start(torch.from_numpy(first[None]).to(dev))                       # ring = 32 x first frame, zero masks
-            for t in range(1, len(clip)):
-                cur = torch.from_numpy(grey_train(clip[t], H, W)[None]).to(dev)
-                torch.cuda.synchronize()
-                start = time.time()
-                r = stream.step(cur)                                                  # one sess.run-equivalent
-                torch.cuda.synchronize()
-                tot_time += time.time() - start
-                if np.asarray(clip[t]).ndim == 3 and np.asarray(clip[t]).shape[:2] == (H, W):
-                    # warpRevBundle2 (deploy_bundle.py:136-146,303) on the device: colour frame remapped by the smoothed maps
-                    bgr = torch.from_numpy(np.ascontiguousarray(clip[t], dtype=np.uint8)).to(dev)
-                    colour_out.append(warp.warpRevBundle2(bgr, r['x_map'], r['y_map']).cpu().numpy())
-                net_output = ((r['output'][0, :, :, 0].cpu().numpy() + 0.5) * 255).clip(0, 255).astype(np.uint8)
-                frames_out.append(net_output)
-                xmaps.append(r['x_map'][0, :, :, 0].cpu().numpy()); ymaps.append(r['y_map'][0, :, :, 0].cpu().numpy())
-                blacks.append(r['black_pix'][0].cpu().numpy().astype(np.uint8))
-                length += 1
-                if length % 10 == 0:
-                    print('length: ' + str(length))
-                    print('fps={}'.format(length / tot_time))
+            if args.pipeline:
+                length, tot_time = run_pipelined(stream, clip, H, W, frames_out, colour_out, xmaps, ymaps, blacks)
+            else:
+                length, tot_time = run_serial(stream, clip, H, W, dev, frames_out, colour_out, xmaps, ymaps, blacks)
         except Exception:
             traceback.print_exc()                    # the reference swallows per-video errors and still finalises
         finally:

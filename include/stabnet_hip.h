@@ -343,6 +343,10 @@ int stabnet_adam_step(float* params, const float* grads, const float* grads2, fl
 int stabnet_warp_rev_bundle2(const unsigned char* img, const float* x_map, const float* y_map, int N, int H, int W, int C,
                              int rate, unsigned char* out, float* workspace, float* px_out, float* py_out, void* stream);
 
+/* cvt_train2img (deploy_bundle.py:75): the network's grey output back to 8 bits, out[i] = uint8((x[i] + 0.5) * 255) clipped to
+ * [0, 255].  x float [n], out uint8 [n].  The 16-byte path needs both pointers 16-byte aligned (any alignment is accepted). */
+int stabnet_cvt_train2img(const float* x, unsigned char* out, long n, void* stream);
+
 /* ---- next to the path: max-inscribed-rectangle crop --------------------------------
  * deploy_bundle.py:291: all_black += round(black) per frame;  :344-366: once per video, the largest black-free rectangle
  * whose top-left corner lies on the `step` (10) grid of the top-left quadrant, first-found-wins on ties. */

@@ -91,6 +91,15 @@ def test_cli_drivers_run(cuda, tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     assert "ignored" in out.stdout and os.path.exists(tmp_path / "output" / "synthetic_stable.npy")
     assert np.load(tmp_path / "output" / "synthetic_stable.npy").shape == (4, 64, 96)
+    # --pipeline (upload / frame / download on three streams): the same files, byte for byte
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "deploy_bundle.py"), "--synthetic", "5", "--height", "64",
+                          "--width", "96", "--pipeline", "--output-dir", str(tmp_path / "p")], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "fps=" in out.stdout, out.stderr[-2000:]
+    assert np.array_equal(np.load(tmp_path / "p" / "output" / "synthetic_stable.npy"), np.load(tmp_path / "output" / "synthetic_stable.npy"))
+    ma, mb = np.load(tmp_path / "p" / "output" / "synthetic_maps.npz"), np.load(tmp_path / "output" / "synthetic_maps.npz")
+    for k in ("x_map", "y_map", "black"):
+        assert np.array_equal(ma[k], mb[k]), k
     # like the reference (restorer.restore, train_bundle_nobm.py:208) the driver refuses to start without the ImageNet backbone ...
     out = subprocess.run([sys.executable, os.path.join(ROOT, "train_bundle_nobm.py"), "--iters", "1", "--batch-size", "2",
                           "--height", "64", "--width", "96", "--model-dir", str(tmp_path / "m0"),

@@ -30,3 +30,19 @@ def test_warp_rev_bundle2(cuda, H, W, shift):
         assert (want == 0).all(axis=2).mean() > 0.1                       # a visible black border: the BORDER_CONSTANT taps were exercised
     got2 = warp.warpRevBundle2(torch.from_numpy(img).to(cuda), torch.from_numpy(x_map).to(cuda), torch.from_numpy(y_map).to(cuda))
     assert np.array_equal(got2.cpu().numpy(), want)                          # (without the optional pixel-coordinate outputs)
+
+
+@pytest.mark.parametrize("n,off", [(1, 0), (7, 0), (4096, 0), (720 * 1280, 0), (1001, 1), (4099, 3)])
+def test_cvt_train2img_exact(cuda, n, off):
+    """deploy_bundle.py:75: ((x + 0.5) * 255).astype(uint8) (clipped first); the vector path and the unaligned / tail path."""
+    import torch
+    from stabnet_amd import warp
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-0.7, 0.7, size=n + off).astype(np.float32)
+    x[: min(n, 4)] = [-0.5, 0.5, 0.49999997, -0.49803922][: min(n, 4)]
+    want = ((x[off:] + np.float32(0.5)) * np.float32(255)).clip(0, 255).astype(np.uint8)
+    xd = torch.from_numpy(x).to(cuda)[off:]
+    buf = torch.zeros(n + off + 8, dtype=torch.uint8, device=cuda)
+    out = warp.cvt_train2img(xd, buf[off:off + n])
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert int(buf[off + n:].sum()) == 0 and int(buf[:off].sum()) == 0        # nothing written outside
