@@ -145,10 +145,12 @@ class StabNetStream:
         self._graph = None
         return self.all_black
 
-    def _enqueue(self, prof=None):
+    def _enqueue(self, prof=None, cur=None):
+        """One frame on the current stream.  cur: the frame to read instead of the fixed staging buffer self.cur (ClipPipeline hands
+        its upload slot over directly)."""
         r = self.reg
         _lib.call("stabnet_deploy_frame", r.plan.handle, ptr(r.params), ptr(r.fold), ptr(self.frames_ring),
-                  ptr(self.masks_ring), self.depth, ptr(self.head_dev), self._lags_c, len(self.lags), ptr(self.cur),
+                  ptr(self.masks_ring), self.depth, ptr(self.head_dev), self._lags_c, len(self.lags), ptr(self.cur if cur is None else cur),
                   self.refine, self.cfg.grid_h, self.cfg.grid_w, self.cfg.do_crop_rate, ptr(self.theta), ptr(self.out_img),
                   ptr(self.black), ptr(self.x_map), ptr(self.y_map), ptr(self.Hs), ptr(self.frame_fb), ptr(self.all_black),
                   ptr(r.workspace), r.workspace.numel(), stream_ptr(r.device), prof.handle if prof is not None else 0,
@@ -227,10 +229,9 @@ class ClipPipeline:
         self.ev_down = [torch.cuda.Event() for _ in range(slots)]
 
     def _frame(self, k: int, maps: bool):
-        """Everything frame-shaped of slot k on the current stream: staging copy, the frame, its results into the slot's buffers."""
+        """Everything frame-shaped of slot k on the current stream: the frame, its results into the slot's buffers."""
         st, H, W = self.st, self.st.H, self.st.W
-        st.cur.copy_(self.d_grey[k])
-        st._enqueue()
+        st._enqueue(cur=self.d_grey[k])                      # the frame reads the upload slot itself: no staging copy
         # cvt_train2img (deploy_bundle.py:75)
         _lib.call("stabnet_cvt_train2img", ptr(st.out_img), ptr(self.d_out[k]), H * W, stream_ptr(self.dev), device=self.dev)
         if self.colour:
