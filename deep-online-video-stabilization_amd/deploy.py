@@ -1,5 +1,6 @@
 """Host side of the online loop (deploy_bundle.py:183-342, the network + feedback part): an on-device history ring
-per stream and ONE C call per frame.  Video decode/encode and the colour remap stay with the caller."""
+per stream and ONE C call per frame (StabNetStream); ClipPipeline drives it from a clip in HOST memory with the PCIe copies
+of neighbouring frames overlapped and the colour remap (warpRevBundle2) on the device.  Video decode/encode stay with the caller."""
 from __future__ import annotations
 
 import ctypes
