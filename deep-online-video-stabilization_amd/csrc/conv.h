@@ -43,7 +43,16 @@ struct Prof;
 // LDS and multiplied by v_mfma_f32_32x32x16_bf16 (fp32 accumulate; tensors stay fp32 in memory).  Never the default: the
 // reference is fp32 end to end.  (A launch argument, not a ConvArgs field: the fp32 kernels' argument block -- and with it their
 // register allocation -- stays exactly what it was; an extra field cost the fp32 path 1 %.)
-int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof = nullptr, int bf16_operands = 0);
+// bf16_operands = 2 / 3: split operands -- exact f32 products as six / nine bf16 MFMAs, both operands split when the fragments
+// are read (conv_kernel.h, sn_split3).  bf16_operands = 4 with w_img: the weights come as a pre-split fragment-major image
+// (conv_weight_image_floats / launch_weight_split_image), only the A fragments are split at run time; launches the packed ring
+// kernel cannot take (register-staged path, in-workgroup split-K) run the exact f32 MFMA kernels on a.w as before.
+int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof = nullptr, int bf16_operands = 0, const float* w_img = nullptr);
+// Pre-split weight image of a convolution whose weights are [Cout][K] rows (K % 32 == 0): per (64-channel N tile, 32-deep K step)
+// 3072 floats = [wave column 2][plane h, m, l][k group 2][lane 64][8 bf16]; lane (n = lane & 31, g = lane >> 5), element e holds
+// k = 32 step + 16 group + 8 (e >> 2) + 4 g + (e & 3) -- the k order of the ring kernel's A fragments.
+size_t conv_weight_image_floats(int Cout, int K);
+int launch_weight_split_image(const float* w, int Cout, int K, float* img, hipStream_t st);
 // 1 if that launch is followed by a split-K reduce launch (0: no split, or the split runs inside the workgroups)
 int conv_reduce_launches(const ConvArgs& a);
 

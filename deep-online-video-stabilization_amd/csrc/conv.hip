@@ -200,17 +200,20 @@ static thread_local int g_bf16_operands = 0;      // set by conv_launch for the 
 // The bf16-operand variant exists for the inference tile (64 x 64 x 32) only.
 static void igemm_variant(const ConvArgs& a, int bm, int bn, int bk, int mode, int& nbuf_out, int& bf16_out) {
     static const int nbuf = env_int("STABNET_CONV_NBUF", 0);          // 0: the rule; 1 / 2: forced
-    bf16_out = (g_bf16_operands && bm == 64 && bn == 64 && bk == 32) ? 1 : 0;
+    bf16_out = (g_bf16_operands && bm == 64 && bn == 64 && bk == 32) ? g_bf16_operands : 0;
     const bool one_stage = nbuf == 1 || (nbuf == 0 && mode == 0 && bm == 64 && bn == 64 && a.M >= 32768);
-    nbuf_out = (!bf16_out && one_stage) ? 1 : 2;
+    nbuf_out = (bf16_out != 1 && one_stage) ? 1 : 2;
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int MODE>
 static int launch_one_t(const ConvArgs& a, hipStream_t st) {
     int nbuf, bf16;
     igemm_variant(a, BM, BN, BK, MODE, nbuf, bf16);
-    if constexpr (BM == 64 && BN == 64 && BK == 32)
-        if (bf16) return launch_one_nb<BM, BN, BK, WM, WN, MODE, 2, 1>(a, st);
+    if constexpr (BM == 64 && BN == 64 && BK == 32) {
+        if (bf16 == 1) return launch_one_nb<BM, BN, BK, WM, WN, MODE, 2, 1>(a, st);
+        else if (bf16 == 2) return nbuf == 1 ? launch_one_nb<BM, BN, BK, WM, WN, MODE, 1, 2>(a, st) : launch_one_nb<BM, BN, BK, WM, WN, MODE, 2, 2>(a, st);
+        else if (bf16 == 3) return nbuf == 1 ? launch_one_nb<BM, BN, BK, WM, WN, MODE, 1, 3>(a, st) : launch_one_nb<BM, BN, BK, WM, WN, MODE, 2, 3>(a, st);
+    }
     return nbuf == 1 ? launch_one_nb<BM, BN, BK, WM, WN, MODE, 1>(a, st) : launch_one_nb<BM, BN, BK, WM, WN, MODE, 2>(a, st);
 }
 
@@ -258,10 +261,43 @@ static int launch_ring_mode(const ConvArgs& a, hipStream_t st) {
     }
     const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64) * a.splitk;
     const int grid = (int)std::min<long>(ntiles, ring_grid_cap());
-    if (g_bf16_operands) conv_ring_f32_kernel<MODE, 1><<<grid, 256, 0, st>>>(a);
+    if (g_bf16_operands == 1) conv_ring_f32_kernel<MODE, 1><<<grid, 256, 0, st>>>(a);
+    else if (g_bf16_operands == 2) conv_ring_f32_kernel<MODE, 2><<<grid, 256, 0, st>>>(a);
+    else if (g_bf16_operands == 3) conv_ring_f32_kernel<MODE, 3><<<grid, 256, 0, st>>>(a);
     else conv_ring_f32_kernel<MODE, 0><<<grid, 256, 0, st>>>(a);
     SN_LAUNCH_CHECK("conv_ring_f32_kernel");
     return STABNET_OK;
+}
+
+static int g_cus = 0;
+static int device_cus() {
+    if (g_cus == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return 0;
+        g_cus = cus;
+    }
+    return g_cus;
+}
+
+// The packed split kernel (conv_ring_kernel.h, BF16 = 4): 60 KiB of LDS per workgroup -> two per CU.
+template <int MODE>
+static int launch_ring_packed_mode(const ConvArgs& a, hipStream_t st) {
+    const int cus = device_cus();
+    if (cus <= 0) {
+        stabnet_set_error("conv: cannot read the CU count");
+        return STABNET_ERR_LAUNCH;
+    }
+    static const int per_cu = env_int("STABNET_CONV_PACKED_WGS_PER_CU", 2);
+    const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64) * a.splitk;
+    const int grid = (int)std::min<long>(ntiles, (long)per_cu * usable_cus(cus));
+    conv_ring_f32_kernel<MODE, 4><<<grid, 256, 0, st>>>(a);
+    SN_LAUNCH_CHECK("conv_ring_f32_kernel<packed>");
+    return STABNET_OK;
+}
+static int launch_ring_packed(const ConvArgs& a, hipStream_t st) {
+    if (a.rowrun) return launch_ring_packed_mode<2>(a, st);
+    return a.pad == 0 ? launch_ring_packed_mode<0>(a, st) : launch_ring_packed_mode<1>(a, st);
 }
 
 static int launch_ring(const ConvArgs& a, hipStream_t st) {
@@ -289,13 +325,13 @@ static bool ring_pro_vectors_ok(const ConvArgs& a) {
 static bool ring_pro_geometry(const ConvArgs& a, bool has_prologue) {
     static const int on = env_int("STABNET_CONV_RING_PRO", 1);
     if (g_ring < 0) g_ring = env_int("STABNET_CONV_RING", 1);
-    return on && g_ring && !g_bf16_operands && !g_force_bk16 && has_prologue && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 &&
+    return on && g_ring && g_bf16_operands != 1 && !g_force_bk16 && has_prologue && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 &&
            a.up == 1 && a.Cin % 32 == 0 && !a.rowrun && a.x_ld == a.Cin;
 }
 static int conv_kgroups(const ConvArgs& a, bool ring, bool has_prologue) {
     static const int on = env_int("STABNET_CONV_KGROUPS", 1);
     static const int on2 = env_int("STABNET_CONV_KGROUPS_PRO", 1);
-    if (!on || a.splitk < 2 || g_bf16_operands) return 1;
+    if (!on || a.splitk < 2 || g_bf16_operands == 1) return 1;
     const int steps = conv_total_steps(a);
     if (a.steps_per_split * a.splitk != steps) return 1;
     if (ring && a.splitk == 3 && !a.rowrun) return 3;
@@ -303,16 +339,6 @@ static int conv_kgroups(const ConvArgs& a, bool ring, bool has_prologue) {
     return 1;
 }
 
-static int g_cus = 0;
-static int device_cus() {
-    if (g_cus == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            return 0;
-        g_cus = cus;
-    }
-    return g_cus;
-}
 
 static int launch_ring_kg(const ConvArgs& a, int kg, hipStream_t st) {
     const int cus = device_cus();
@@ -322,9 +348,16 @@ static int launch_ring_kg(const ConvArgs& a, int kg, hipStream_t st) {
     }
     const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64);
     const int grid = (int)std::min<long>(ntiles, usable_cus(cus));     // 144 (102) KiB of LDS: one workgroup per CU
-    if (kg == 2) conv_ring_f32_kernel<0, 0, 2, 1><<<grid, 512, 0, st>>>(a);
-    else if (a.pad == 0) conv_ring_f32_kernel<0, 0, 3><<<grid, 768, 0, st>>>(a);
-    else conv_ring_f32_kernel<1, 0, 3><<<grid, 768, 0, st>>>(a);
+#define SN_KG_LAUNCH(B)                                                                  \
+    do {                                                                                  \
+        if (kg == 2) conv_ring_f32_kernel<0, B, 2, 1><<<grid, 512, 0, st>>>(a);           \
+        else if (a.pad == 0) conv_ring_f32_kernel<0, B, 3><<<grid, 768, 0, st>>>(a);      \
+        else conv_ring_f32_kernel<1, B, 3><<<grid, 768, 0, st>>>(a);                      \
+    } while (0)
+    if (g_bf16_operands == 2) SN_KG_LAUNCH(2);
+    else if (g_bf16_operands == 3) SN_KG_LAUNCH(3);
+    else SN_KG_LAUNCH(0);
+#undef SN_KG_LAUNCH
     SN_LAUNCH_CHECK("conv_ring_f32_kernel<KG>");
     return STABNET_OK;
 }
@@ -337,7 +370,7 @@ static int launch_ring_kg(const ConvArgs& a, int kg, hipStream_t st) {
 static bool ring_pro_eligible(const ConvArgs& a) {
     static const int on = env_int("STABNET_CONV_RING_PRO", 1);
     if (g_ring < 0) g_ring = env_int("STABNET_CONV_RING", 1);
-    return on && g_ring && !g_bf16_operands && !g_force_bk16 && a.in_scale != nullptr && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 &&
+    return on && g_ring && g_bf16_operands != 1 && !g_force_bk16 && a.in_scale != nullptr && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 &&
            a.up == 1 && a.Cin % 32 == 0 && a.out_scale == nullptr && a.out_floor == nullptr && !a.rowrun && a.x_ld == a.Cin &&
            ring_pro_vectors_ok(a);
 }
@@ -354,7 +387,9 @@ static int launch_ring_pro(ConvArgs a, long delta, hipStream_t st) {
     a.out_floor = reinterpret_cast<const float*>((size_t)delta);      // the kernel's pair distance (not a pointer: see conv_ring_kernel.h PRO)
     const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64) * a.splitk;
     const int grid = (int)std::min<long>(ntiles, ring_grid_cap());
-    conv_ring_f32_kernel<0, 0, 1, 1><<<grid, 256, 0, st>>>(a);
+    if (g_bf16_operands == 2) conv_ring_f32_kernel<0, 2, 1, 1><<<grid, 256, 0, st>>>(a);
+    else if (g_bf16_operands == 3) conv_ring_f32_kernel<0, 3, 1, 1><<<grid, 256, 0, st>>>(a);
+    else conv_ring_f32_kernel<0, 0, 1, 1><<<grid, 256, 0, st>>>(a);
     SN_LAUNCH_CHECK("conv_ring_f32_kernel<PRO>");
     return STABNET_OK;
 }
@@ -369,8 +404,45 @@ int conv_reduce_launches(const ConvArgs& a) {
     return (t == T64x64 && conv_kgroups(a, ring, a.in_scale_expected != 0) > 1) ? 0 : 1;
 }
 
-int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands) {
+// ---- pre-split weight image (conv.h) -----------------------------------------------------------------------------------
+size_t conv_weight_image_floats(int Cout, int K) { return (size_t)cdiv(Cout, 64) * (size_t)(K / 32) * 3072; }
+
+__global__ __launch_bounds__(256) void weight_split_image_kernel(const float* __restrict__ w, int Cout, int K, uint4* __restrict__ img) {
+    // one thread per (N tile, K step, wave column, k group, lane): 8 weights -> three 16-byte plane entries
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int steps = K / 32;
+    const long total = (long)((Cout + 63) / 64) * steps * 256;
+    if (i >= total) return;
+    const int lane = (int)(i & 63), j = (int)((i >> 6) & 1), wn = (int)((i >> 7) & 1);
+    const long ts = i >> 8;                                  // nt * steps + ks
+    const int ks = (int)(ts % steps), nt = (int)(ts / steps);
+    const int n = nt * 64 + wn * 32 + (lane & 31), g = lane >> 5;
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+    if (n < Cout) {
+        const float* r = w + (size_t)n * K + ks * 32 + 16 * j + 4 * g;
+        lo = *reinterpret_cast<const f32x4*>(r);
+        hi = *reinterpret_cast<const f32x4*>(r + 8);
+    }
+    const SnSplit3 a = sn_split3(lo), b = sn_split3(hi);
+    uint4* out = img + ts * 768 + (size_t)(wn * 6 + j) * 64 + lane;       // 16-byte units: stage 768, chunk 64
+    out[0] = __builtin_bit_cast(uint4, SN_CAT8(a.h, b.h));
+    out[2 * 64] = __builtin_bit_cast(uint4, SN_CAT8(a.m, b.m));
+    out[4 * 64] = __builtin_bit_cast(uint4, SN_CAT8(a.l, b.l));
+}
+
+int launch_weight_split_image(const float* w, int Cout, int K, float* img, hipStream_t st) {
+    SN_REQUIRE(w && img && Cout > 0 && K > 0 && K % 32 == 0, "weight image: K=%d must be a multiple of 32", K);
+    const long total = (long)cdiv(Cout, 64) * (K / 32) * 256;
+    weight_split_image_kernel<<<cdiv(total, 256), 256, 0, st>>>(w, Cout, K, reinterpret_cast<uint4*>(img));
+    SN_LAUNCH_CHECK("weight_split_image_kernel");
+    return STABNET_OK;
+}
+
+int conv_launch(const ConvArgs& a_in, hipStream_t st, Prof* prof, int bf16_operands, const float* w_img) {
+    const bool want_packed = bf16_operands == 4 && w_img != nullptr;
+    if (bf16_operands == 4) bf16_operands = 0;               // every path but the packed ring kernel is the exact f32 one
     g_bf16_operands = bf16_operands;
+    const ConvArgs& a = a_in;
     SN_REQUIRE(a.rowrun || a.Cin % 16 == 0, "conv: Cin=%d must be a multiple of 16 (pad the channels)", a.Cin);
     SN_REQUIRE(!a.rowrun || (a.in_scale == nullptr && a.up == 1 && a.KH <= 8 && cdiv(a.KW * a.Cin, 32) <= 4),
                "conv: row-run operand needs no prologue, KH <= 8 and KW*Cin <= 128");
@@ -386,7 +458,12 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands
     SN_REQUIRE(ring || a.x_ld == a.Cin, "conv: a strided input (x_ld %d != Cin %d) needs the ring kernel", a.x_ld, a.Cin);
     const int kg = (t == T64x64) ? conv_kgroups(a, ring, a.in_scale != nullptr) : 1;
     const bool pro = kg == 1 && !ring && t == T64x64 && bk32 && ring_pro_eligible(a);
-    if (pro) {
+    const bool packed = want_packed && ring && kg == 1 && !pro && a.K % 32 == 0;
+    if (packed) {
+        ConvArgs b = a;
+        b.w = w_img;
+        rc = launch_ring_packed(b, st);
+    } else if (pro) {
         rc = launch_ring_pro(a, 0, st);
     } else if (kg > 1) {
         rc = launch_ring_kg(a, kg, st);
@@ -403,6 +480,7 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof, int bf16_operands
     }
     const int mode = (a.up > 1 || a.rowrun) ? 2 : (a.pad == 0 ? 0 : 1);
     int kind = PK_KERNEL_CONV_RING + mode + (bf16_operands ? 3 : 0);
+    if (packed) kind = PK_KERNEL_CONV_PACKED + mode;
     if (pro) {
         kind = PK_KERNEL_CONV_KG + 2;
     } else if (kg > 1) {

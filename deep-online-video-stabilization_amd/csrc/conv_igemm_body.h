@@ -204,7 +204,29 @@
         if (ks + 1 < ks_end) load_tiles();                // global loads in flight under the MFMAs
         const float* Ab = smem + buf * STAGE + (wm * WM) * PITCH + frag_off;
         const float* Bb = smem + buf * STAGE + (BM + wn * WN) * PITCH + frag_off;
-        if constexpr (BF16) {
+        if constexpr (BF16 >= 2) {
+            // split mode (conv_kernel.h, sn_split3): exact f32 products as six (nine) bf16 MFMAs per 16-deep k group
+            typedef float fl4 __attribute__((ext_vector_type(4)));
+            static_assert(BK % 16 == 0, "split operands need BK % 16 == 0");
+#pragma unroll
+            for (int kp = 0; kp < BK / 16; ++kp) {
+                SnSplit3 al[TM], ah[TM], bl[TN], bh[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    al[i] = sn_split3(*reinterpret_cast<const fl4*>(Ab + i * 32 * PITCH + (2 * kp) * 8));
+                    ah[i] = sn_split3(*reinterpret_cast<const fl4*>(Ab + i * 32 * PITCH + (2 * kp + 1) * 8));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bl[j] = sn_split3(*reinterpret_cast<const fl4*>(Bb + j * 32 * PITCH + (2 * kp) * 8));
+                    bh[j] = sn_split3(*reinterpret_cast<const fl4*>(Bb + j * 32 * PITCH + (2 * kp + 1) * 8));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) sn_mfma_split3<(BF16 == 3) ? 9 : 6>(acc[i][j], al[i], ah[i], bl[j], bh[j]);
+            }
+        } else if constexpr (BF16) {
             // bf16-operand mode (conv_launch's bf16_operands): two 8-deep fragment pairs -> one v_mfma_f32_32x32x16_bf16
             typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
             typedef float fl4 __attribute__((ext_vector_type(4)));

@@ -139,6 +139,57 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const ConvA
     }
 }
 
+// ---- exact float32 products on the bf16 matrix pipe (BF16 template value 2: six partial products, 3: all nine) ------------------
+// gfx950 multiplies f32 operands at 1/16 of its bf16 MFMA rate (v_mfma_f32_32x32x2_f32: 64 cycles for 2 k; v_mfma_f32_32x32x16_bf16:
+// 32 cycles for 16 k).  A float32 is EXACTLY the sum of three bf16 numbers: h = bf16(x) (round to nearest: 8 significant bits),
+// m = bf16(x - h) (the difference is exact in f32 and has at most 16 significant bits), l = x - h - m (exact, at most 8 bits, so its
+// conversion is exact too) -- barring underflow of l below 2^-126 and non-finite x.  Every bf16 x bf16 product is exact in the f32
+// accumulator's input precision, so a.b = sum over the nine (a_i, b_j) pairs with f32 accumulation is the f32 product; the three pairs
+// (m,l), (l,m), (l,l) are below 2^-23 |a.b| together and are dropped in the six-product form (same order as ONE f32 rounding of the
+// product).  Small terms are accumulated first.  Cost: 5.5 VALU per operand element and 6 (9) x 32 cycles of matrix pipe per 32-deep
+// stage instead of 1024.
+typedef __bf16 sn_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 sn_bf16x8 __attribute__((ext_vector_type(8)));
+struct SnSplit3 { sn_bf16x4 h, m, l; };
+__device__ __forceinline__ SnSplit3 sn_split3(const f32x4 x) {
+    SnSplit3 s;
+    s.h = __builtin_convertvector(x, sn_bf16x4);
+    const f32x4 r = x - __builtin_convertvector(s.h, f32x4);
+    s.m = __builtin_convertvector(r, sn_bf16x4);
+    const f32x4 r2 = r - __builtin_convertvector(s.m, f32x4);
+    s.l = __builtin_convertvector(r2, sn_bf16x4);
+    return s;
+}
+#define SN_CAT8(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
+// acc += A . B for one 16-deep k group: (a0, a1) / (b0, b1) are the two 4-deep halves of the lane's 8 k values.
+template <int NPROD>
+__device__ __forceinline__ void sn_mfma_split3(f32x16& acc, const SnSplit3& a0, const SnSplit3& a1, const SnSplit3& b0, const SnSplit3& b1) {
+    const sn_bf16x8 ah = SN_CAT8(a0.h, a1.h), am = SN_CAT8(a0.m, a1.m), al = SN_CAT8(a0.l, a1.l);
+    const sn_bf16x8 bh = SN_CAT8(b0.h, b1.h), bm = SN_CAT8(b0.m, b1.m), bl = SN_CAT8(b0.l, b1.l);
+    if constexpr (NPROD == 9) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bl, acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+// The same six products with B already split (planes as 8 x bf16 in four registers each: the packed weight image).
+__device__ __forceinline__ void sn_mfma_split3_pk(f32x16& acc, const SnSplit3& a0, const SnSplit3& a1, const f32x4 bh_, const f32x4 bm_, const f32x4 bl_) {
+    const sn_bf16x8 ah = SN_CAT8(a0.h, a1.h), am = SN_CAT8(a0.m, a1.m), al = SN_CAT8(a0.l, a1.l);
+    const sn_bf16x8 bh = __builtin_bit_cast(sn_bf16x8, bh_), bm = __builtin_bit_cast(sn_bf16x8, bm_), bl = __builtin_bit_cast(sn_bf16x8, bl_);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
 // MODE 0: no padding and no dilation (1x1 convs, any stride): every tap of every row < M is in frame -> no masks.
 // MODE 1: zero padding: a per-row bit mask (one bit per filter tap, built once) says which taps are in frame.
 // MODE 2: dilated input (dgrad of a strided conv): validity and address are recomputed per tap (slow path).

@@ -59,17 +59,20 @@ __device__ unsigned long long g_ring_stamps[4096 * 8];
 #define SN_STAMP_RT(i) do { } while (0)
 #endif
 
-typedef __bf16 sn_bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 sn_bf16x8 __attribute__((ext_vector_type(8)));
-
 template <int MODE /* 0: no padding, 1: zero padding, 2: row-run A operand on a zero-BORDERED image (ConvArgs::rowrun) */,
           int BF16 = 0 /* 1: fragments rounded to bf16 at read time, v_mfma_f32_32x32x16_bf16 (conv_launch's bf16_operands) */,
           int KG = 1 /* K groups of 4 waves: split-K inside the workgroup (p.splitk == KG), see the header comment */,
           int PRO = 0 /* 1: BN + ReLU prologue on the A fragments (MODE 0 only); KG = 1: the pair of towers as one launch */>
 __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs p) {
     constexpr int BM = 64, BN = 64, BK = 32;
-    constexpr int STAGE = (BM + BN) * BK;                  // floats
-    static_assert(!PRO || (MODE == 0 && BF16 == 0), "the fragment prologue exists for the 1x1 fp32 kernel");
+    // BF16 == 4 ("packed split"): the B operand is a pre-split, fragment-major IMAGE of the weights (conv.hip,
+    // weight_split_image_kernel): per (N tile, K step) 12 KiB = [wave column 2][plane h/m/l 3][k group 2][lane 64][8 bf16], copied
+    // linearly by three DMAs per wave and read lane-linearly (conflict-free), so only the A fragments are split at run time.
+    constexpr bool PK = (BF16 == 4);
+    constexpr int B_STAGE = PK ? 3072 : BN * BK;           // floats
+    constexpr int STAGE = BM * BK + B_STAGE;               // floats
+    static_assert(!PRO || (MODE == 0 && BF16 != 1 && !PK), "the fragment prologue exists for the 1x1 fp32 / split kernels");
+    static_assert(!PK || KG == 1, "the packed split kernel has no in-workgroup split-K yet");
     constexpr int SC_FLOATS = PRO ? 3 * 4 * 64 : 0;        // per group, stage and wave: 32 scales + 32 shifts, behind the rings
     __shared__ __attribute__((aligned(16))) float ring[KG * 3 * STAGE + KG * SC_FLOATS];
 
@@ -183,14 +186,14 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
             l_tap = ks_begin / run_steps;                  // filter row kh
             l_kw = ks_begin - l_tap * run_steps;           // run step s within the row
             xb = p.x + ((long)l_tap * (p.W + 2 * p.pad) * p.Cin + 32 * l_kw);
-            wb = p.w + (size_t)ks_begin * BK;
+            wb = PK ? p.w + ((size_t)nt * total_steps + ks_begin) * B_STAGE : p.w + (size_t)ks_begin * BK;
         } else {
             l_tap = ks_begin / cin_steps;
             l_c0 = (ks_begin - l_tap * cin_steps) * BK;
             const int l_kh = l_tap / p.KW;
             l_kw = l_tap - l_kh * p.KW;
             xb = p.x + ((l_kh * p.W + l_kw) * ld + l_c0 - pad_off);
-            wb = p.w + (l_tap * p.Cin + l_c0);
+            wb = PK ? p.w + ((size_t)nt * total_steps + ks_begin) * B_STAGE : p.w + (l_tap * p.Cin + l_c0);
             if constexpr (PRO) {
                 const bool t2 = m0 >= m_tower;             // tile of the second tower: its tensors live `pair_delta` floats further on
                 if (t2) xb += pair_delta - (long)m_tower * ld;
@@ -211,6 +214,8 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
         const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
         const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
         const float* base = reinterpret_cast<const float*>((size_t)(((unsigned long long)hi << 32) | lo));
+        // (PK: under the packed kernel's scalar-register pressure the wave-uniform LDS address can live in a vector register)
+        if constexpr (PK) lds_byte = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_byte);
         asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(base), "s"(lds_byte) : "memory", "m0");
     };
     auto issue_s = [&](int slot) {                         // PRO: this wave's copy of the step's scales | shifts (4 B per lane)
@@ -233,9 +238,11 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
             dma16(xb, a_voff[t], lds_byte);
         }
     };
+    const unsigned wimg_voff = (unsigned)(wave * 1024 + lane * 16);          // PK: lane's byte offset inside a DMA chunk pair (+ 4096 t)
     auto issue_b = [&](int slot, int t) {
         if (pt >= t_end || (RING_ABLATE & 1)) return;
-        dma16(wb, w_voff[t], dma_base + (unsigned)(slot * STAGE * 4 + BM * BK * 4 + t * 4096));
+        if constexpr (PK) dma16(wb, wimg_voff + (unsigned)(t * 4096), dma_base + (unsigned)(slot * STAGE * 4 + BM * BK * 4 + t * 4096));
+        else dma16(wb, w_voff[t], dma_base + (unsigned)(slot * STAGE * 4 + BM * BK * 4 + t * 4096));
     };
     auto issue_advance = [&]() {
         if (pt >= t_end) return;
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
             return;
         }
         xb += BK;
-        wb += BK;
+        wb += PK ? B_STAGE : BK;
         if constexpr (PRO) scb += BK;
         if constexpr (MODE == 2) {
             if (++l_kw == run_steps) { l_kw = 0; ++l_tap; xb += (p.W + 2 * p.pad) * p.Cin - BK * run_steps; }
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     auto issue_part = [&](int slot, int part) {
         if (part == 0) issue_a(slot, 0);
         else if (part == 1) { issue_a(slot, 1); issue_b(slot, 0); }
-        else if (part == 2) { issue_b(slot, 1); if constexpr (PRO) issue_s(slot); }
+        else if (part == 2) { issue_b(slot, 1); if constexpr (PK) issue_b(slot, 2); if constexpr (PRO) issue_s(slot); }
         else issue_advance();
     };
     auto issue = [&](int slot) {
@@ -325,6 +332,18 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 #define SN_READ1(kk, off) do { SN_DS_READ(a1, SN_RA1, a_frag[kk], off); SN_DS_READ(b1, SN_RB1, b_frag[kk], off); } while (0)
 #define SN_WAIT0() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA0(a0), "+" SN_RB0(b0))
 #define SN_WAIT1() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA1(a1), "+" SN_RB1(b1))
+    // PK: A fragments alone, and the six pre-split B fragments of a stage (k group j: planes h, m, l), lane-linear
+#define SN_PH0 "{v[132:135]}"
+#define SN_PM0 "{v[136:139]}"
+#define SN_PL0 "{v[140:143]}"
+#define SN_PH1 "{v[144:147]}"
+#define SN_PM1 "{v[148:151]}"
+#define SN_PL1 "{v[152:155]}"
+#define SN_READA(dst, reg, kk, off) SN_DS_READ(dst, reg, a_frag[kk], off)
+#define SN_READB0(off) do { SN_DS_READ(ph0, SN_PH0, bimg_frag, (off) + 0); SN_DS_READ(pm0, SN_PM0, bimg_frag, (off) + 2048); SN_DS_READ(pl0, SN_PL0, bimg_frag, (off) + 4096); } while (0)
+#define SN_READB1(off) do { SN_DS_READ(ph1, SN_PH1, bimg_frag, (off) + 1024); SN_DS_READ(pm1, SN_PM1, bimg_frag, (off) + 3072); SN_DS_READ(pl1, SN_PL1, bimg_frag, (off) + 5120); } while (0)
+#define SN_WAITP0() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA0(a0), "+" SN_RA1(a1), "+" SN_PH0(ph0), "+" SN_PM0(pm0), "+" SN_PL0(pl0))
+#define SN_WAITP1() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA0(a0), "+" SN_RA1(a1), "+" SN_PH1(ph1), "+" SN_PM1(pm1), "+" SN_PL1(pl1))
     // PRO: the fragment's 4 scales + 4 shifts ride with it (this wave's own copy: offset slot * 1024 selects the stage)
 #define SN_RS0 "{v[116:119]}"
 #define SN_RH0 "{v[120:123]}"
@@ -364,6 +383,8 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     // freed slot first serves as the epilogue's transposition scratch; stage k+3 is issued after it, behind one more barrier.
     f32x4 a0, b0, a1, b1;
     f32x4 sc0, sh0, sc1, sh1;                              // PRO only
+    f32x4 ph0, pm0, pl0, ph1, pm1, pl1;                    // PK only: 8 bf16 each
+    const unsigned bimg_frag = lds_base + (unsigned)(4 * BM * BK + wn * 6144 + lane * 16);
     unsigned s_frag[4] = {0u, 0u, 0u, 0u};
     if constexpr (PRO) {
 #pragma unroll
@@ -373,12 +394,13 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     issue(0);
     issue(1);
     // (a wave has 4 DMAs per stage in flight, 5 with the scales of the PRO form)
-    if (remaining > 1) { if constexpr (PRO) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    if (remaining > 1) { if constexpr (PRO || PK) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SN_BARRIER();
     SN_STAMP(1);
     issue(2);
-    if constexpr (PRO) SN_READ0P(0, 0, 0); else SN_READ0(0, 0);
+    if constexpr (PK) { SN_READA(a0, SN_RA0, 0, 0); SN_READA(a1, SN_RA1, 1, 0); SN_READB0(0); }
+    else if constexpr (PRO) SN_READ0P(0, 0, 0); else SN_READ0(0, 0);
 
     // One K-step on ring slot SLOT; returns false after the workgroup's last step.
     auto step = [&](auto slot_c) -> bool {
@@ -386,7 +408,63 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
         constexpr int OFF = SLOT * STAGE * 4;
         constexpr int OFF_NEXT = ((SLOT + 1) % 3) * STAGE * 4;
         bool tile_done, more;
-        if constexpr (BF16) {
+        if constexpr (PK) {
+            // packed split: A fragments kk = 0, 1 (k group 0) and the B planes of k group 0 are in flight at entry
+            SN_WAITP0();
+            const SnSplit3 A0 = sn_split3(a0), A1 = sn_split3(a1);
+            __builtin_amdgcn_sched_barrier(0);
+            SN_READA(a0, SN_RA0, 2, OFF); SN_READA(a1, SN_RA1, 3, OFF); SN_READB1(OFF);
+            __builtin_amdgcn_sched_barrier(0);
+            sn_mfma_split3_pk(acc[0][0], A0, A1, ph0, pm0, pl0);
+            __builtin_amdgcn_sched_barrier(0);
+            SN_WAITP1();                                       // every fragment of this stage is in registers
+            const SnSplit3 C0 = sn_split3(a0), C1 = sn_split3(a1);
+            __builtin_amdgcn_sched_barrier(0);
+            --remaining;
+            tile_done = (--c_left == 0);
+            more = remaining > 0;
+            const bool feed = more && !tile_done;
+            if (more) {
+                if (remaining > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SN_BARRIER();
+                SN_READA(a0, SN_RA0, 0, OFF_NEXT); SN_READA(a1, SN_RA1, 1, OFF_NEXT); SN_READB0(OFF_NEXT);
+            }
+            if (feed) { issue_part(SLOT, 0); issue_part(SLOT, 1); issue_part(SLOT, 2); issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0); }
+            sn_mfma_split3_pk(acc[0][0], C0, C1, ph1, pm1, pl1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (BF16 >= 2) {
+            // split mode (conv_kernel.h, sn_split3): every fragment is decomposed into three bf16 terms when it is read and the stage
+            // is six (nine) v_mfma_f32_32x32x16_bf16 per 16-deep k group instead of eight v_mfma_f32_32x32x2_f32.  Same k
+            // permutation as the bf16-operand branch below.
+            constexpr int NPROD = (BF16 == 3) ? 9 : 6;
+            constexpr int SOFF = SLOT * 1024, SOFF_NEXT = ((SLOT + 1) % 3) * 1024;
+            if constexpr (PRO) { SN_WAIT0P(); SN_PRO(a0, sc0, sh0); } else SN_WAIT0();
+            const SnSplit3 A0 = sn_split3(a0), B0 = sn_split3(b0);
+            if constexpr (PRO) SN_READ1P(1, OFF, SOFF); else SN_READ1(1, OFF);
+            if constexpr (PRO) { SN_WAIT1P(); SN_PRO(a1, sc1, sh1); } else SN_WAIT1();
+            const SnSplit3 A1 = sn_split3(a1), B1 = sn_split3(b1);
+            if constexpr (PRO) { SN_READ0P(2, OFF, SOFF); SN_READ1P(3, OFF, SOFF); } else { SN_READ0(2, OFF); SN_READ1(3, OFF); }
+            sn_mfma_split3<NPROD>(acc[0][0], A0, A1, B0, B1);
+            if constexpr (PRO) { SN_WAIT0P(); SN_WAIT1P(); SN_PRO(a0, sc0, sh0); SN_PRO(a1, sc1, sh1); }
+            else { SN_WAIT0(); SN_WAIT1(); }                   // every fragment of this stage is in registers
+            const SnSplit3 C0 = sn_split3(a0), D0 = sn_split3(b0);
+            const SnSplit3 C1 = sn_split3(a1), D1 = sn_split3(b1);
+            __builtin_amdgcn_sched_barrier(0);
+            --remaining;
+            tile_done = (--c_left == 0);
+            more = remaining > 0;
+            const bool feed = more && !tile_done;
+            if (more) {
+                if (remaining > 1) { if constexpr (PRO) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SN_BARRIER();
+                if constexpr (PRO) SN_READ0P(0, OFF_NEXT, SOFF_NEXT); else SN_READ0(0, OFF_NEXT);
+            }
+            if (feed) { issue_part(SLOT, 0); issue_part(SLOT, 1); issue_part(SLOT, 2); issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0); }
+            sn_mfma_split3<NPROD>(acc[0][0], C0, C1, D0, D1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (BF16) {
             // bf16-operand mode: the four 8-deep fragment pairs of the stage feed TWO v_mfma_f32_32x32x16_bf16.  A lane half
             // holds k = {4h..4h+3} of fragment kk and of fragment kk+1: a permutation of the 16 k of the instruction that is
             // the same for A and B, so the product sum is the same set of terms.  The matrix pipe is no longer the limit
@@ -509,7 +587,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
         if (feed) { issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0); }
         }
         if (tile_done) {
-            if (more) { if constexpr (PRO) SN_WAIT0P(); else SN_WAIT0(); }   // the next tile's first fragments: landed before the epilogue code
+            if (more) { if constexpr (PK) SN_WAITP0(); else if constexpr (PRO) SN_WAIT0P(); else SN_WAIT0(); }   // the next tile's first fragments: landed before the epilogue code
             else SN_BARRIER();                             // (otherwise the barrier above already retired slot SLOT)
             SN_STAMP(2);
             if constexpr (KG > 1) {
@@ -584,4 +662,9 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 #undef SN_WAIT0P
 #undef SN_WAIT1P
 #undef SN_PRO
+#undef SN_READA
+#undef SN_READB0
+#undef SN_READB1
+#undef SN_WAITP0
+#undef SN_WAITP1
 }

@@ -46,6 +46,7 @@ struct Step {
     long in_off, out_off, res_off, w_off, b_off, bn_off;
     long obn_off;                                // inference only: folded BN + ReLU of the CONSUMER fused behind this conv
     int inf_preactivated;                        // inference only: the input tensor already holds relu(bn(.)) -> no prologue
+    long wimg_off;                               // inference only: this conv's pre-split weight image inside the image region of `fold`
     long fvec_off;                               // inference only: per-channel (bias, scale, shift, floor) vectors of a merged
                                                  // shortcut|conv1 launch, offset inside the merge region of `fold` (-1: none)
     // S_CONV_B2B (inference plans): `conv` is the unit's 3x3 conv2 (in_off, w_off; its consumer BN bn2 = mid_obn_off), `conv_b` its
@@ -114,6 +115,7 @@ struct Net {
     struct MergeInfo { long off; int depth, dbn; long b_sc, bn1; };
     std::vector<MergeInfo> merges;                // merged shortcut|conv1 launches of the inference plan
     size_t merge_floats = 0;
+    size_t wimg_floats = 0;                       // inference plans: pre-split weight images of every convolution (conv.h), behind the merge vectors
     PackTable packs{};                            // dgrad weight re-pack of every unit conv (training)
     long pack_w3[16] = {0}, pack_w2[16] = {0}, pack_w1[16] = {0}, pack_sc[16] = {0};   // wt offsets per unit                     // re-laid-out stem weights [64][7][roundup(7*in_ch, 32)] behind the folded BN
     std::vector<UnitInfo> units;
@@ -206,7 +208,7 @@ static Step conv_step(Net& net, const TensorRef& in, const TensorRef& out, int K
     net.splitk_bytes = std::max(net.splitk_bytes, s.splitk_bytes);
     s.in_off = in.off; s.out_off = out.off; s.res_off = res ? res->off : NONE;
     s.w_off = w_off; s.b_off = b_off; s.bn_off = bn_off;
-    s.obn_off = NONE; s.inf_preactivated = 0; s.fvec_off = NONE;
+    s.obn_off = NONE; s.inf_preactivated = 0; s.fvec_off = NONE; s.wimg_off = NONE;
     net.flops += 2.0 * a.M * (double)(a.KH * a.KW * (real_cin ? real_cin : a.Cin)) * a.Cout;   // algorithmic (un-padded)
     return s;
 }
@@ -497,6 +499,13 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             if (st_.pair_ok) net->splitk_bytes = std::max(net->splitk_bytes, bytes);
         }
     }
+    if (!net->keep_all) {  // pre-split weight images for the packed split kernel (stabnet_net_set_bf16_operands(net, 4))
+        for (Step& st_ : net->steps) {
+            if (st_.kind != S_CONV || st_.conv.K % 32 != 0) continue;
+            st_.wimg_off = (long)net->wimg_floats;
+            net->wimg_floats += conv_weight_image_floats(st_.conv.Cout, st_.conv.K);
+        }
+    }
     net->act_floats = ar.peak;
     net->splitk_bytes = std::max(net->splitk_bytes, sizeof(float) * (size_t)N * std::max(8, gap_chunks(net->t_last.H * net->t_last.W)) * net->t_last.C);
     net->max_net = std::max({net->max_net, net->t_c1.size, net->t_pool.size});
@@ -546,7 +555,8 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
                     a.relu_out = 0;
                 }
                 a.partial = splitk;
-                rc = conv_launch(a, st, prof, net->bf16_operands);
+                rc = conv_launch(a, st, prof, net->bf16_operands,
+                                 (net->bf16_operands == 4 && s.wimg_off >= 0) ? fold + 2 * net->G + net->stem_w_floats + net->merge_floats + s.wimg_off : nullptr);
                 break;
             }
             case S_CONV_B2B: {
@@ -701,6 +711,9 @@ const char* stabnet_prof_kind_name(int kind) {
     if (kind == PK_KERNEL_CONV_RING + 3) return "conv_ring_f32_kernel<0, 1, 1, 0>";
     if (kind == PK_KERNEL_CONV_RING + 4) return "conv_ring_f32_kernel<1, 1, 1, 0>";
     if (kind == PK_KERNEL_CONV_RING + 5) return "conv_ring_f32_kernel<2, 1, 1, 0>";
+    if (kind == PK_KERNEL_CONV_PACKED) return "conv_ring_f32_kernel<0, 4, 1, 0>";
+    if (kind == PK_KERNEL_CONV_PACKED + 1) return "conv_ring_f32_kernel<1, 4, 1, 0>";
+    if (kind == PK_KERNEL_CONV_PACKED + 2) return "conv_ring_f32_kernel<2, 4, 1, 0>";
     if (kind == PK_KERNEL_CONV_B2B) return "conv_b2b_f32_kernel<2>";
     if (kind == PK_KERNEL_CONV_B2B + 1) return "conv_b2b_f32_kernel<4>";
     if (kind >= PK_KERNEL_CONV_BASE && kind < PK_KERNEL_CONV_BASE + 72) {
@@ -737,7 +750,7 @@ int stabnet_net_set_bf16_operands(void* netp, int on) {
     Net* net = static_cast<Net*>(netp);
     SN_REQUIRE(net != nullptr, "set_bf16_operands: null net");
     SN_REQUIRE(!net->keep_all || !on, "set_bf16_operands: inference plans only (training stays fp32)");
-    net->bf16_operands = on ? 1 : 0;
+    net->bf16_operands = (on >= 1 && on <= 4) ? on : 0;     // 1: bf16 operands; 2 / 3: split operands (conv_kernel.h sn_split3)
     return STABNET_OK;
 }
 
@@ -817,16 +830,26 @@ int stabnet_net_fold_bn(const void* netp, const float* params, float* fold, floa
                                   fold + 2 * net->G + net->stem_w_floats + m.off, (hipStream_t)stream);
         if (rc) return rc;
     }
-    if (!net->stem_rowrun) return STABNET_OK;
-    // stem weights OHWI [64][7][7][in_ch_pad] -> row-run layout [64][7][roundup(7*in_ch, 32)] (zeros in the run padding)
-    return launch_stem_repack(params + net->w_stem, fold + 2 * net->G, 64, 7, 7, net->in_ch_pad, net->in_ch,
-                              (hipStream_t)stream);
+    if (net->stem_rowrun) {
+        // stem weights OHWI [64][7][7][in_ch_pad] -> row-run layout [64][7][roundup(7*in_ch, 32)] (zeros in the run padding)
+        rc = launch_stem_repack(params + net->w_stem, fold + 2 * net->G, 64, 7, 7, net->in_ch_pad, net->in_ch, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    // pre-split weight images (inference plans): from the weights each launch reads
+    float* img = fold + 2 * net->G + net->stem_w_floats + net->merge_floats;
+    for (const Step& s : net->steps) {
+        if (s.kind != S_CONV || s.wimg_off < 0) continue;
+        const float* w = s.conv.rowrun ? fold + 2 * net->G : params + s.w_off;
+        rc = launch_weight_split_image(w, s.conv.Cout, s.conv.K, img + s.wimg_off, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return STABNET_OK;
 }
 
 /* Floats of the `fold` buffer: [G scales][G shifts][re-laid-out stem weights of an inference plan]. */
 size_t stabnet_net_fold_floats(const void* netp) {
     const Net* net = static_cast<const Net*>(netp);
-    return net ? 2 * net->G + net->stem_w_floats + net->merge_floats : 0;
+    return net ? 2 * net->G + net->stem_w_floats + net->merge_floats + net->wimg_floats : 0;
 }
 
 /* get_resnet(x_tensor, is_training=False): x_tensor NHWC [N,H,W,in_ch] -> theta [N,n_theta]. */

@@ -94,7 +94,7 @@ class Regressor:
             raise _lib.StabnetError("Regressor needs a GPU device; there is no CPU fallback")
         self.plan = NetPlan(N, H, W, cfg, keep_activations)
         if bf16_operands:              # secondary fast mode (bf16 conv operands, fp32 accumulate); default is exact fp32
-            _lib.call("stabnet_net_set_bf16_operands", self.plan.handle, 1)
+            _lib.call("stabnet_net_set_bf16_operands", self.plan.handle, int(bf16_operands))
         flat = params if isinstance(params, np.ndarray) and params.ndim == 1 else self.plan.pack(params)
         self.params = torch.from_numpy(np.ascontiguousarray(flat)).to(self.device)
         self.fold = torch.empty(int(_lib.lib().stabnet_net_fold_floats(self.plan.handle)), dtype=torch.float32, device=self.device)
