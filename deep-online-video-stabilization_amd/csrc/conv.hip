@@ -456,7 +456,11 @@ int conv_launch(const ConvArgs& a_in, hipStream_t st, Prof* prof, int bf16_opera
     const bool rec = prof != nullptr && prof->begin(st);
     const bool ring = ring_eligible(a, t);
     SN_REQUIRE(ring || a.x_ld == a.Cin, "conv: a strided input (x_ld %d != Cin %d) needs the ring kernel", a.x_ld, a.Cin);
-    const int kg = (t == T64x64) ? conv_kgroups(a, ring, a.in_scale != nullptr) : 1;
+    int kg = (t == T64x64) ? conv_kgroups(a, ring, a.in_scale != nullptr) : 1;
+    // the packed split kernel has no in-workgroup split-K (60 KiB of ring per group): a ring launch that would split K three ways
+    // inside the workgroup goes through the slabs + reduce launch instead
+    static const int packed_kg3 = env_int("STABNET_CONV_PACKED_KG3", 1);
+    if (want_packed && packed_kg3 && ring && kg == 3 && a.K % 32 == 0 && a.partial != nullptr) kg = 1;
     const bool pro = kg == 1 && !ring && t == T64x64 && bk32 && ring_pro_eligible(a);
     const bool packed = want_packed && ring && kg == 1 && !pro && a.K % 32 == 0;
     if (packed) {

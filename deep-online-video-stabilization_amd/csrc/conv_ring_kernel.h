@@ -342,8 +342,42 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 #define SN_READA(dst, reg, kk, off) SN_DS_READ(dst, reg, a_frag[kk], off)
 #define SN_READB0(off) do { SN_DS_READ(ph0, SN_PH0, bimg_frag, (off) + 0); SN_DS_READ(pm0, SN_PM0, bimg_frag, (off) + 2048); SN_DS_READ(pl0, SN_PL0, bimg_frag, (off) + 4096); } while (0)
 #define SN_READB1(off) do { SN_DS_READ(ph1, SN_PH1, bimg_frag, (off) + 1024); SN_DS_READ(pm1, SN_PM1, bimg_frag, (off) + 3072); SN_DS_READ(pl1, SN_PL1, bimg_frag, (off) + 5120); } while (0)
-#define SN_WAITP0() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA0(a0), "+" SN_RA1(a1), "+" SN_PH0(ph0), "+" SN_PM0(pm0), "+" SN_PL0(pl0))
-#define SN_WAITP1() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_RA0(a0), "+" SN_RA1(a1), "+" SN_PH1(ph1), "+" SN_PM1(pm1), "+" SN_PL1(pl1))
+#define SN_RA2 "{v[156:159]}"
+#define SN_RA3 "{v[160:163]}"
+    // waits of the packed schedule: LDS operations return in order, so lgkmcnt(N) says "everything but the youngest N reads has landed"
+    // (a scalar load in flight can only make such a wait stricter)
+#define SN_WAIT_A01(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+" SN_RA0(a0), "+" SN_RA1(a1))
+#define SN_WAIT_A23B0(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+" SN_RA2(a2), "+" SN_RA3(a3), "+" SN_PH0(ph0), "+" SN_PM0(pm0), "+" SN_PL0(pl0))
+#define SN_WAIT_B1() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_PH1(ph1), "+" SN_PM1(pm1), "+" SN_PL1(pl1))
+#define SN_READA4(off) do { SN_READA(a0, SN_RA0, 0, off); SN_READA(a1, SN_RA1, 1, off); SN_READA(a2, SN_RA2, 2, off); SN_READA(a3, SN_RA3, 3, off); } while (0)
+#define SN_SB() __builtin_amdgcn_sched_barrier(0)
+#define SN_PMFMA(ap, breg) do { if (!(RING_ABLATE & 8)) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sn_bf16x8, ap), __builtin_bit_cast(sn_bf16x8, breg), acc[0][0], 0, 0, 0); else acc[0][0][0] += __builtin_bit_cast(float, ap.x) + breg.x; SN_SB(); } while (0)
+    // one pair of a fragment's floats through one split level (conv_kernel.h): L1 -> plane h, L2 -> plane m, L3 -> plane l
+#define SN_L1(P, c, x0, x1) do { if (!(RING_ABLATE & 32)) P.h.c = sn_split_level(x0, x1); else P.h.c = __builtin_bit_cast(unsigned, x0); } while (0)
+#define SN_L2(P, c, x0, x1) do { if (!(RING_ABLATE & 32)) P.m.c = sn_split_level(x0, x1); else P.m.c = __builtin_bit_cast(unsigned, x1); } while (0)
+#define SN_L3(P, c, x0, x1) do { if (!(RING_ABLATE & 32)) P.l.c = sn_pack_bf16(x0, x1); else P.l.c = __builtin_bit_cast(unsigned, x0); } while (0)
+    // first MFMA group of a packed step (planes AP x B planes of k group 0) with the split of k group 1 (a2, a3 -> CP) in its gaps
+#define SN_PK_GROUP0(OFF_)                                                                                               \
+    SN_READB1(OFF_);                                       /* (their registers were the last MFMA's operands) */          \
+    SN_WAIT_A23B0(3);                                                                                                    \
+    float x0 = a2.x, x1 = a2.y, x2 = a2.z, x3 = a2.w, x4 = a3.x, x5 = a3.y, x6 = a3.z, x7 = a3.w;                        \
+    SN_SB();                                                                                                             \
+    SN_PMFMA(AP.l, ph0); SN_L1(CP, x, x0, x1); SN_L1(CP, y, x2, x3); SN_SB();                                            \
+    SN_PMFMA(AP.h, pl0); SN_L1(CP, z, x4, x5); SN_L1(CP, w, x6, x7); SN_SB();                                            \
+    SN_PMFMA(AP.m, pm0); SN_L2(CP, x, x0, x1); SN_L2(CP, y, x2, x3); SN_SB();                                            \
+    SN_PMFMA(AP.m, ph0); SN_L2(CP, z, x4, x5); SN_L2(CP, w, x6, x7); SN_SB();                                            \
+    SN_PMFMA(AP.h, pm0); SN_L3(CP, x, x0, x1); SN_L3(CP, y, x2, x3); SN_L3(CP, z, x4, x5); SN_L3(CP, w, x6, x7); SN_SB(); \
+    SN_PMFMA(AP.h, ph0)
+    // last four MFMAs of the second group (planes CP x B planes of k group 1) with the split of the NEXT stage's k group 0 (-> AP)
+#define SN_PK_GROUP1_TAIL()                                                                                              \
+    SN_WAIT_A01(5);                                        /* (a2, a3 and the B planes of the next stage may still fly) */ \
+    float y0 = a0.x, y1 = a0.y, y2 = a0.z, y3 = a0.w, y4 = a1.x, y5 = a1.y, y6 = a1.z, y7 = a1.w;                        \
+    SN_SB();                                                                                                             \
+    SN_PMFMA(CP.m, pm1); SN_L1(AP, x, y0, y1); SN_L1(AP, y, y2, y3); SN_SB();                                            \
+    SN_PMFMA(CP.m, ph1); SN_L1(AP, z, y4, y5); SN_L1(AP, w, y6, y7); SN_SB();                                            \
+    SN_PMFMA(CP.h, pm1); SN_L2(AP, x, y0, y1); SN_L2(AP, y, y2, y3); SN_SB();                                            \
+    SN_PMFMA(CP.h, ph1); SN_L2(AP, z, y4, y5); SN_L2(AP, w, y6, y7);                                                     \
+    SN_L3(AP, x, y0, y1); SN_L3(AP, y, y2, y3); SN_L3(AP, z, y4, y5); SN_L3(AP, w, y6, y7); SN_SB()
     // PRO: the fragment's 4 scales + 4 shifts ride with it (this wave's own copy: offset slot * 1024 selects the stage)
 #define SN_RS0 "{v[116:119]}"
 #define SN_RH0 "{v[120:123]}"
@@ -384,6 +418,8 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     f32x4 a0, b0, a1, b1;
     f32x4 sc0, sh0, sc1, sh1;                              // PRO only
     f32x4 ph0, pm0, pl0, ph1, pm1, pl1;                    // PK only: 8 bf16 each
+    f32x4 a2, a3;                                          // PK only: A fragments kk = 2, 3
+    SnPlanes AP, CP;                                       // PK only: split A planes of k group 0 / 1
     const unsigned bimg_frag = lds_base + (unsigned)(4 * BM * BK + wn * 6144 + lane * 16);
     unsigned s_frag[4] = {0u, 0u, 0u, 0u};
     if constexpr (PRO) {
@@ -399,8 +435,12 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     SN_BARRIER();
     SN_STAMP(1);
     issue(2);
-    if constexpr (PK) { SN_READA(a0, SN_RA0, 0, 0); SN_READA(a1, SN_RA1, 1, 0); SN_READB0(0); }
-    else if constexpr (PRO) SN_READ0P(0, 0, 0); else SN_READ0(0, 0);
+    if constexpr (PK) {
+        SN_READA4(0); SN_READB0(0);
+        SN_WAIT_A01(5);
+        AP = sn_split3_pair(a0, a1);
+        SN_SB();
+    } else if constexpr (PRO) SN_READ0P(0, 0, 0); else SN_READ0(0, 0);
 
     // One K-step on ring slot SLOT; returns false after the workgroup's last step.
     auto step = [&](auto slot_c) -> bool {
@@ -409,30 +449,26 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
         constexpr int OFF_NEXT = ((SLOT + 1) % 3) * STAGE * 4;
         bool tile_done, more;
         if constexpr (PK) {
-            // packed split: A fragments kk = 0, 1 (k group 0) and the B planes of k group 0 are in flight at entry
-            SN_WAITP0();
-            const SnSplit3 A0 = sn_split3(a0), A1 = sn_split3(a1);
-            __builtin_amdgcn_sched_barrier(0);
-            SN_READA(a0, SN_RA0, 2, OFF); SN_READA(a1, SN_RA1, 3, OFF); SN_READB1(OFF);
-            __builtin_amdgcn_sched_barrier(0);
-            sn_mfma_split3_pk(acc[0][0], A0, A1, ph0, pm0, pl0);
-            __builtin_amdgcn_sched_barrier(0);
-            SN_WAITP1();                                       // every fragment of this stage is in registers
-            const SnSplit3 C0 = sn_split3(a0), C1 = sn_split3(a1);
-            __builtin_amdgcn_sched_barrier(0);
+            // packed split, software-pipelined: at entry AP holds the split planes of k group 0 of this stage (made during the previous
+            // step's second MFMA group); a2, a3 (k group 1) and the B planes of k group 0 were read behind the previous barrier.
+            // Every split level sits between two MFMAs (sched_barrier pins the order): a 32-cycle MFMA hides about six plain VALU.
+            SN_PK_GROUP0(OFF);
             --remaining;
             tile_done = (--c_left == 0);
             more = remaining > 0;
             const bool feed = more && !tile_done;
+            SN_WAIT_B1();                                      // every fragment of this stage is in registers
             if (more) {
                 if (remaining > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 SN_BARRIER();
-                SN_READA(a0, SN_RA0, 0, OFF_NEXT); SN_READA(a1, SN_RA1, 1, OFF_NEXT); SN_READB0(OFF_NEXT);
+                SN_READA4(OFF_NEXT); SN_READB0(OFF_NEXT);
             }
-            if (feed) { issue_part(SLOT, 0); issue_part(SLOT, 1); issue_part(SLOT, 2); issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0); }
-            sn_mfma_split3_pk(acc[0][0], C0, C1, ph1, pm1, pl1);
-            __builtin_amdgcn_sched_barrier(0);
+            SN_PMFMA(CP.l, ph1);
+            if (feed) { issue_part(SLOT, 0); issue_part(SLOT, 1); SN_SB(); }
+            SN_PMFMA(CP.h, pl1);
+            if (feed) { issue_part(SLOT, 2); issue_part(SLOT, 3); SN_SB(); }
+            SN_PK_GROUP1_TAIL();
         } else if constexpr (BF16 >= 2) {
             // split mode (conv_kernel.h, sn_split3): every fragment is decomposed into three bf16 terms when it is read and the stage
             // is six (nine) v_mfma_f32_32x32x16_bf16 per 16-deep k group instead of eight v_mfma_f32_32x32x2_f32.  Same k
@@ -587,7 +623,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
         if (feed) { issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0); }
         }
         if (tile_done) {
-            if (more) { if constexpr (PK) SN_WAITP0(); else if constexpr (PRO) SN_WAIT0P(); else SN_WAIT0(); }   // the next tile's first fragments: landed before the epilogue code
+            if (more) { if constexpr (PK) SN_WAIT_A23B0(0); else if constexpr (PRO) SN_WAIT0P(); else SN_WAIT0(); }   // the next tile's first fragments: landed before the epilogue code
             else SN_BARRIER();                             // (otherwise the barrier above already retired slot SLOT)
             SN_STAMP(2);
             if constexpr (KG > 1) {
@@ -642,10 +678,67 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
         }
         return more;
     };
+    // PK: a step in the middle of a tile for both sides of the ring (the consumer stays inside its tile, the producer inside its own,
+    // at least two more steps follow): the same instruction stream as `step` without its tile bookkeeping -- with the matrix work of
+    // a step down to 12 x 32 cycles, the ~70 scalar instructions and ~10 branches of the general step were what a wave spent its time on
+    auto fast_step = [&](auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int OFF = SLOT * STAGE * 4;
+        constexpr int OFF_NEXT = ((SLOT + 1) % 3) * STAGE * 4;
+        if constexpr (PK) {
+            SN_PK_GROUP0(OFF);
+            --remaining; --c_left; --p_left;
+            SN_WAIT_B1();
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            SN_BARRIER();
+            SN_READA4(OFF_NEXT); SN_READB0(OFF_NEXT);
+            SN_PMFMA(CP.l, ph1);
+            if (!(RING_ABLATE & 1)) {
+                const unsigned lds_a = dma_base + (unsigned)(SLOT * STAGE * 4);
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const float* src = ((a_mask[t] >> l_tap) & 1ull) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(xb) + a_voff[t]) : zero_page;
+                        __builtin_amdgcn_global_load_lds((sn_gbl_ptr_t)src, (sn_lds_ptr_t)(size_t)(lds_a + (unsigned)(t * 4096)), 16, 0, 0);
+                    }
+                } else {
+                    dma16(xb, a_voff[0], lds_a);
+                    dma16(xb, a_voff[1], lds_a + 4096u);
+                }
+                dma16(wb, wimg_voff, lds_a + (unsigned)(BM * BK * 4));
+            }
+            SN_SB();
+            SN_PMFMA(CP.h, pl1);
+            if (!(RING_ABLATE & 1)) {
+                const unsigned lds_b = dma_base + (unsigned)(SLOT * STAGE * 4 + BM * BK * 4);
+                dma16(wb, wimg_voff + 4096u, lds_b + 4096u);
+                dma16(wb, wimg_voff + 8192u, lds_b + 8192u);
+            }
+            xb += BK;
+            wb += B_STAGE;
+            if constexpr (MODE == 2) {
+                if (++l_kw == run_steps) { l_kw = 0; ++l_tap; xb += (p.W + 2 * p.pad) * p.Cin - BK * run_steps; }
+            } else {
+                l_c0 += BK;
+                if (l_c0 == p.Cin) {
+                    l_c0 = 0;
+                    ++l_tap;
+                    xb += ld - p.Cin;
+                    if (++l_kw == p.KW) { l_kw = 0; xb += row_jump; }
+                }
+            }
+            SN_SB();
+            SN_PK_GROUP1_TAIL();
+        }
+    };
     using s0 = std::integral_constant<int, 0>;
     using s1 = std::integral_constant<int, 1>;
     using s2 = std::integral_constant<int, 2>;
     while (true) {
+        if constexpr (PK) {
+            int nf = (pt < t_end) ? min(min(c_left, p_left) - 1, remaining - 2) : 0;
+            for (; nf >= 3; nf -= 3) { fast_step(s0{}); fast_step(s1{}); fast_step(s2{}); }
+        }
         if (!step(s0{})) break;
         if (!step(s1{})) break;
         if (!step(s2{})) break;
@@ -665,6 +758,15 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 #undef SN_READA
 #undef SN_READB0
 #undef SN_READB1
-#undef SN_WAITP0
-#undef SN_WAITP1
+#undef SN_WAIT_A01
+#undef SN_WAIT_A23B0
+#undef SN_WAIT_B1
+#undef SN_READA4
+#undef SN_SB
+#undef SN_PMFMA
+#undef SN_L1
+#undef SN_L2
+#undef SN_L3
+#undef SN_PK_GROUP0
+#undef SN_PK_GROUP1_TAIL
 }

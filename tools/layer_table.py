@@ -12,11 +12,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--height", type=int, default=720); ap.add_argument("--width", type=int, default=1280)
 ap.add_argument("--streams", type=int, default=1); ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--bf16", action="store_true", help="the secondary bf16-operand mode (shows each layer's non-MFMA floor)")
+ap.add_argument("--mode", type=int, default=0, help="conv operand mode (stabnet_net_set_bf16_operands): 2 / 3 split, 4 packed split")
 a = ap.parse_args()
 cfg = Config(height=a.height, width=a.width)
 P = synthetic.make_params(cfg, 0, 0.2)
 clip = torch.from_numpy(synthetic.make_clip(a.height, a.width, 4, 1234)).cuda()
-s = StabNetStream(P, a.height, a.width, cfg, streams=a.streams, bf16_operands=a.bf16)
+s = StabNetStream(P, a.height, a.width, cfg, streams=a.streams, bf16_operands=(1 if a.bf16 else a.mode))
 fr = [clip[t:t+1].expand(a.streams, a.height, a.width).contiguous() for t in range(4)]
 s.start(fr[0])
 for i in range(5): s.step(fr[i % 4])

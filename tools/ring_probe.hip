@@ -2,6 +2,9 @@
 //   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -DRING_ABLATE=<mask> -I deep-online-video-stabilization_amd/csrc -o /tmp/ring_probe tools/ring_probe.hip
 // mask bits: 1 no DMA, 2 no barrier, 4 no ds_read, 8 no MFMA.   args: H W Cin Cout KH [workgroups]   (stride 1, SAME padding)
 #include "conv_ring_kernel.h"
+#ifndef PROBE_BF16
+#define PROBE_BF16 0          // 4: the packed split kernel (w is then a weight image: 1.5 x the floats, zeros here)
+#endif
 #include <cstdio>
 #include <vector>
 #include <algorithm>
@@ -15,8 +18,8 @@ int main(int argc, char** argv) {
     const int M = Ho * Wo, K = stem ? KH * ((KH * Cin + 31) / 32 * 32) : KH * KH * Cin;
     ConvArgs a{};
     float *x, *w, *y;
-    (void)hipMalloc(&x, (size_t)(H + 8) * (W + 8) * Cin * 4 + 1024); (void)hipMalloc(&w, (size_t)N * K * 4); (void)hipMalloc(&y, (size_t)M * N * 4);
-    (void)hipMemset(x, 0, (size_t)(H + 8) * (W + 8) * Cin * 4 + 1024); (void)hipMemset(w, 0, (size_t)N * K * 4);
+    (void)hipMalloc(&x, (size_t)(H + 8) * (W + 8) * Cin * 4 + 1024); (void)hipMalloc(&w, (size_t)(N + 64) * K * 6 + 4096); (void)hipMalloc(&y, (size_t)M * N * 4);
+    (void)hipMemset(x, 0, (size_t)(H + 8) * (W + 8) * Cin * 4 + 1024); (void)hipMemset(w, 0, (size_t)(N + 64) * K * 6 + 4096);
     a.x = x; a.w = w; a.y = y; a.N = 1; a.H = H; a.W = W; a.Cin = Cin; a.Cout = N; a.KH = KH; a.KW = KH; a.stride = st_; a.pad = KH / 2; a.rowrun = stem ? 1 : 0;
     a.up = 1; a.Ho = Ho; a.Wo = Wo; a.res_H = Ho; a.res_W = Wo; a.res_stride = 1; a.M = M; a.K = K; a.splitk = 1;
     a.x_ld = a.Cin; a.res_ld = a.Cout; a.xcd_swizzle = getenv("NOSWZ") ? 0 : 1;
@@ -27,9 +30,9 @@ int main(int argc, char** argv) {
     const int wgs = argc > 6 ? atoi(argv[6]) : 768;
     const int g1 = (int)std::min<size_t>(nblk, (size_t)wgs);
     auto launch = [&]() {
-        if (stem) conv_ring_f32_kernel<2><<<g1, 256>>>(a);
-        else if (KH == 1) conv_ring_f32_kernel<0><<<g1, 256>>>(a);
-        else conv_ring_f32_kernel<1><<<g1, 256>>>(a);
+        if (stem) conv_ring_f32_kernel<2, PROBE_BF16><<<g1, 256>>>(a);
+        else if (KH == 1) conv_ring_f32_kernel<0, PROBE_BF16><<<g1, 256>>>(a);
+        else conv_ring_f32_kernel<1, PROBE_BF16><<<g1, 256>>>(a);
     };
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) launch();
@@ -38,7 +41,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 20; ++i) launch();
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 20;
-    printf("ABLATE=%2d M=%d K=%d N=%d blocks=%zu (%.2f/CU): %.1f us  %.1f TFLOP/s nominal\n", RING_ABLATE, M, K, N, nblk, nblk / 256.0,
+    printf("BF16=%d ABLATE=%2d M=%d K=%d N=%d blocks=%zu (%.2f/CU): %.1f us  %.1f TFLOP/s nominal\n", PROBE_BF16, RING_ABLATE, M, K, N, nblk, nblk / 256.0,
            ms * 1e3, 2.0 * M * K * N / ms / 1e9);
 #if RING_STAMP
     {   // timeline of the LAST launch: per workgroup (wave 0) s_memtime at entry / first stage landed / before the epilogue of

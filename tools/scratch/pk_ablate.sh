@@ -1,0 +1,11 @@
+#!/bin/bash
+# ablations of the packed split kernel (tools/ring_probe.hip, -DPROBE_BF16=4): 1 no DMA, 4 no ds_read, 8 no MFMA, 32 no split VALU
+for geo in "90 160 128 128 3" "45 80 512 1280 1" "720 1280 13 64 7"; do
+  set -- $geo
+  stem=0; [ "$5" = "7" ] && stem=1
+  echo "== H=$1 W=$2 Cin=$3 N=$4 KH=$5"
+  tools/bin/ring_probe_f32_0 $1 $2 $3 $4 $5 768 $stem
+  for ab in 0 1 4 8 32 40 41 45; do tools/bin/ring_probe_pk_$ab $1 $2 $3 $4 $5 512 $stem; done
+  tools/bin/ring_probe_pk_0 $1 $2 $3 $4 $5 256 $stem
+  tools/bin/ring_probe_pk_0 $1 $2 $3 $4 $5 768 $stem
+done

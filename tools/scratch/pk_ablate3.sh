@@ -1,0 +1,7 @@
+#!/bin/bash
+for geo in "90 160 128 128 3" "45 80 512 1280 1" "720 1280 13 64 7"; do
+  set -- $geo
+  stem=0; [ "$5" = "7" ] && stem=1
+  echo "== H=$1 W=$2 Cin=$3 N=$4 KH=$5"
+  for ab in 0 45; do tools/bin/ring_probe_pk_$ab $1 $2 $3 $4 $5 512 $stem; done
+done
