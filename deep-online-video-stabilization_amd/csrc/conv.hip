@@ -291,6 +291,13 @@ static int launch_ring_packed_mode(const ConvArgs& a, hipStream_t st) {
     static const int per_cu = env_int("STABNET_CONV_PACKED_WGS_PER_CU", 2);
     const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64) * a.splitk;
     const int grid = (int)std::min<long>(ntiles, (long)per_cu * usable_cus(cus));
+    if constexpr (MODE == 0) {
+        if (a.in_scale != nullptr) {                          // BN + ReLU prologue on the A fragments (the inference conv1 layers)
+            conv_ring_f32_kernel<0, 4, 1, 1><<<grid, 256, 0, st>>>(a);
+            SN_LAUNCH_CHECK("conv_ring_f32_kernel<packed, PRO>");
+            return STABNET_OK;
+        }
+    }
     conv_ring_f32_kernel<MODE, 4><<<grid, 256, 0, st>>>(a);
     SN_LAUNCH_CHECK("conv_ring_f32_kernel<packed>");
     return STABNET_OK;
@@ -462,7 +469,13 @@ int conv_launch(const ConvArgs& a_in, hipStream_t st, Prof* prof, int bf16_opera
     static const int packed_kg3 = env_int("STABNET_CONV_PACKED_KG3", 1);
     if (want_packed && packed_kg3 && ring && kg == 3 && a.K % 32 == 0 && a.partial != nullptr) kg = 1;
     const bool pro = kg == 1 && !ring && t == T64x64 && bk32 && ring_pro_eligible(a);
-    const bool packed = want_packed && ring && kg == 1 && !pro && a.K % 32 == 0;
+    // packed split kernel with the fragment prologue: 1x1 / stride 1 layers that carry an input BN + ReLU (register-staged kernel or
+    // the two-group PRO ring form otherwise); a K split goes through the slabs + reduce launch
+    static const int packed_pro_on = env_int("STABNET_CONV_PACKED_PRO", 1);
+    const bool packed_pro = want_packed && packed_pro_on && !ring && t == T64x64 && bk32 && a.in_scale != nullptr && ring_pro_geometry(a, true) &&
+                            ring_pro_vectors_ok(a) && (a.splitk == 1 || a.partial != nullptr);
+    if (packed_pro) kg = 1;
+    const bool packed = (want_packed && ring && kg == 1 && !pro && a.K % 32 == 0) || packed_pro;
     if (packed) {
         ConvArgs b = a;
         b.w = w_img;
@@ -484,8 +497,9 @@ int conv_launch(const ConvArgs& a_in, hipStream_t st, Prof* prof, int bf16_opera
     }
     const int mode = (a.up > 1 || a.rowrun) ? 2 : (a.pad == 0 ? 0 : 1);
     int kind = PK_KERNEL_CONV_RING + mode + (bf16_operands ? 3 : 0);
-    if (packed) kind = PK_KERNEL_CONV_PACKED + mode;
-    if (pro) {
+    if (packed) {
+        kind = packed_pro ? PK_KERNEL_CONV_PACKED + 3 : PK_KERNEL_CONV_PACKED + mode;
+    } else if (pro) {
         kind = PK_KERNEL_CONV_KG + 2;
     } else if (kg > 1) {
         kind = kg == 2 ? PK_KERNEL_CONV_KG + 3 : PK_KERNEL_CONV_KG + mode;

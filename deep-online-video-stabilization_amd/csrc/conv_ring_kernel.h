@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     constexpr bool PK = (BF16 == 4);
     constexpr int B_STAGE = PK ? 3072 : BN * BK;           // floats
     constexpr int STAGE = BM * BK + B_STAGE;               // floats
-    static_assert(!PRO || (MODE == 0 && BF16 != 1 && !PK), "the fragment prologue exists for the 1x1 fp32 / split kernels");
+    static_assert(!PRO || (MODE == 0 && BF16 != 1), "the fragment prologue exists for the 1x1 fp32 / split kernels");
     static_assert(!PK || KG == 1, "the packed split kernel has no in-workgroup split-K yet");
     constexpr int SC_FLOATS = PRO ? 3 * 4 * 64 : 0;        // per group, stage and wave: 32 scales + 32 shifts, behind the rings
     __shared__ __attribute__((aligned(16))) float ring[KG * 3 * STAGE + KG * SC_FLOATS];
@@ -104,8 +104,9 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 
     // PRO: the pair of towers (see the header comment)
     // (KG > 1 with PRO -- the inference conv1 layers that split K -- is one tower and out_floor is an ordinary floor vector)
-    const long pair_delta = (PRO && KG == 1) ? (long)(size_t)p.out_floor : 0L;
-    const int m_tower = (PRO && KG == 1 && pair_delta != 0) ? (p.M >> 1) : 0x7fffffff;
+    // (the packed split form -- inference conv1 layers -- is one tower as well)
+    const long pair_delta = (PRO && KG == 1 && !PK) ? (long)(size_t)p.out_floor : 0L;
+    const int m_tower = (PRO && KG == 1 && !PK && pair_delta != 0) ? (p.M >> 1) : 0x7fffffff;
     const unsigned sc_base = (KG > 1) ? (unsigned)(size_t)(sn_lds_ptr_t)ring + (unsigned)(KG * 3 * STAGE * 4) + (unsigned)grp * (unsigned)(SC_FLOATS * 4)
                                       : lds_base + 3u * STAGE * 4u;   // [slot][wave][scale 32 | shift 32]
     // consumer steps of this workgroup (every slice has steps_per_split steps except the last one)
@@ -346,8 +347,30 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 #define SN_RA3 "{v[160:163]}"
     // waits of the packed schedule: LDS operations return in order, so lgkmcnt(N) says "everything but the youngest N reads has landed"
     // (a scalar load in flight can only make such a wait stricter)
-#define SN_WAIT_A01(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+" SN_RA0(a0), "+" SN_RA1(a1))
-#define SN_WAIT_A23B0(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+" SN_RA2(a2), "+" SN_RA3(a3), "+" SN_PH0(ph0), "+" SN_PM0(pm0), "+" SN_PL0(pl0))
+#define SN_RS2 "{v[164:167]}"
+#define SN_RH2 "{v[168:171]}"
+#define SN_RS3 "{v[172:175]}"
+#define SN_RH3 "{v[176:179]}"
+    // (PRO: the scale / shift fragments of the four A fragments are read IN FRONT of them, so the same counts cover them)
+#define SN_WAIT_A01(n)                                                                                                     \
+    do {                                                                                                                   \
+        if constexpr (PRO) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+" SN_RA0(a0), "+" SN_RA1(a1), "+" SN_RS0(sc0), "+" SN_RH0(sh0), "+" SN_RS1(sc1), "+" SN_RH1(sh1)); \
+        else asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+" SN_RA0(a0), "+" SN_RA1(a1));                                  \
+    } while (0)
+#define SN_WAIT_A23B0(n)                                                                                                   \
+    do {                                                                                                                   \
+        if constexpr (PRO) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+" SN_RA2(a2), "+" SN_RA3(a3), "+" SN_PH0(ph0), "+" SN_PM0(pm0), "+" SN_PL0(pl0), "+" SN_RS2(sc2), "+" SN_RH2(sh2), "+" SN_RS3(sc3), "+" SN_RH3(sh3)); \
+        else asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+" SN_RA2(a2), "+" SN_RA3(a3), "+" SN_PH0(ph0), "+" SN_PM0(pm0), "+" SN_PL0(pl0)); \
+    } while (0)
+#define SN_READS8(soff)                                                                                                    \
+    do {                                                                                                                   \
+        if constexpr (PRO) {                                                                                               \
+            SN_DS_READ(sc0, SN_RS0, s_frag[0], soff); SN_DS_READ(sh0, SN_RH0, s_frag[0], (soff) + 128);                    \
+            SN_DS_READ(sc1, SN_RS1, s_frag[1], soff); SN_DS_READ(sh1, SN_RH1, s_frag[1], (soff) + 128);                    \
+            SN_DS_READ(sc2, SN_RS2, s_frag[2], soff); SN_DS_READ(sh2, SN_RH2, s_frag[2], (soff) + 128);                    \
+            SN_DS_READ(sc3, SN_RS3, s_frag[3], soff); SN_DS_READ(sh3, SN_RH3, s_frag[3], (soff) + 128);                    \
+        }                                                                                                                  \
+    } while (0)
 #define SN_WAIT_B1() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_PH1(ph1), "+" SN_PM1(pm1), "+" SN_PL1(pl1))
 #define SN_READA4(off) do { SN_READA(a0, SN_RA0, 0, off); SN_READA(a1, SN_RA1, 1, off); SN_READA(a2, SN_RA2, 2, off); SN_READA(a3, SN_RA3, 3, off); } while (0)
 #define SN_SB() __builtin_amdgcn_sched_barrier(0)
@@ -360,6 +383,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 #define SN_PK_GROUP0(OFF_)                                                                                               \
     SN_READB1(OFF_);                                       /* (their registers were the last MFMA's operands) */          \
     SN_WAIT_A23B0(3);                                                                                                    \
+    if constexpr (PRO) { SN_PRO(a2, sc2, sh2); SN_PRO(a3, sc3, sh3); }                                                   \
     float x0 = a2.x, x1 = a2.y, x2 = a2.z, x3 = a2.w, x4 = a3.x, x5 = a3.y, x6 = a3.z, x7 = a3.w;                        \
     SN_SB();                                                                                                             \
     SN_PMFMA(AP.l, ph0); SN_L1(CP, x, x0, x1); SN_L1(CP, y, x2, x3); SN_SB();                                            \
@@ -371,6 +395,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     // last four MFMAs of the second group (planes CP x B planes of k group 1) with the split of the NEXT stage's k group 0 (-> AP)
 #define SN_PK_GROUP1_TAIL()                                                                                              \
     SN_WAIT_A01(5);                                        /* (a2, a3 and the B planes of the next stage may still fly) */ \
+    if constexpr (PRO) { SN_PRO(a0, sc0, sh0); SN_PRO(a1, sc1, sh1); }                                                   \
     float y0 = a0.x, y1 = a0.y, y2 = a0.z, y3 = a0.w, y4 = a1.x, y5 = a1.y, y6 = a1.z, y7 = a1.w;                        \
     SN_SB();                                                                                                             \
     SN_PMFMA(CP.m, pm1); SN_L1(AP, x, y0, y1); SN_L1(AP, y, y2, y3); SN_SB();                                            \
@@ -419,6 +444,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     f32x4 sc0, sh0, sc1, sh1;                              // PRO only
     f32x4 ph0, pm0, pl0, ph1, pm1, pl1;                    // PK only: 8 bf16 each
     f32x4 a2, a3;                                          // PK only: A fragments kk = 2, 3
+    f32x4 sc2, sh2, sc3, sh3;                              // PK + PRO only
     SnPlanes AP, CP;                                       // PK only: split A planes of k group 0 / 1
     const unsigned bimg_frag = lds_base + (unsigned)(4 * BM * BK + wn * 6144 + lane * 16);
     unsigned s_frag[4] = {0u, 0u, 0u, 0u};
@@ -430,14 +456,15 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     issue(0);
     issue(1);
     // (a wave has 4 DMAs per stage in flight, 5 with the scales of the PRO form)
-    if (remaining > 1) { if constexpr (PRO || PK) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    if (remaining > 1) { if constexpr (PRO && PK) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if constexpr (PRO || PK) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SN_BARRIER();
     SN_STAMP(1);
     issue(2);
     if constexpr (PK) {
-        SN_READA4(0); SN_READB0(0);
+        SN_READS8(0); SN_READA4(0); SN_READB0(0);
         SN_WAIT_A01(5);
+        if constexpr (PRO) { SN_PRO(a0, sc0, sh0); SN_PRO(a1, sc1, sh1); }
         AP = sn_split3_pair(a0, a1);
         SN_SB();
     } else if constexpr (PRO) SN_READ0P(0, 0, 0); else SN_READ0(0, 0);
@@ -459,10 +486,10 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
             const bool feed = more && !tile_done;
             SN_WAIT_B1();                                      // every fragment of this stage is in registers
             if (more) {
-                if (remaining > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                if (remaining > 1) { if constexpr (PRO) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 SN_BARRIER();
-                SN_READA4(OFF_NEXT); SN_READB0(OFF_NEXT);
+                SN_READS8(((SLOT + 1) % 3) * 1024); SN_READA4(OFF_NEXT); SN_READB0(OFF_NEXT);
             }
             SN_PMFMA(CP.l, ph1);
             if (feed) { issue_part(SLOT, 0); issue_part(SLOT, 1); SN_SB(); }
@@ -657,7 +684,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
                     conv_epilogue<1, 1, true>(acc, p, c_m0 + wm * 32, c_n0 + wn * 32, lane, 0,
                                               lds_base + (unsigned)(OFF + wave * SN_EPI_WAVE_BYTES));
                 }
-            } else if constexpr (PRO)
+            } else if constexpr (PRO && !PK)
             conv_epilogue<1, 1, false, true>(acc, p, c_m0 + wm * 32, c_n0 + wn * 32, lane, c_z,
                                              lds_base + (unsigned)(OFF + wave * SN_EPI_WAVE_BYTES), c_yoff, c_roff);
             else
@@ -689,9 +716,9 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
             SN_PK_GROUP0(OFF);
             --remaining; --c_left; --p_left;
             SN_WAIT_B1();
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            if constexpr (PRO) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             SN_BARRIER();
-            SN_READA4(OFF_NEXT); SN_READB0(OFF_NEXT);
+            SN_READS8(((SLOT + 1) % 3) * 1024); SN_READA4(OFF_NEXT); SN_READB0(OFF_NEXT);
             SN_PMFMA(CP.l, ph1);
             if (!(RING_ABLATE & 1)) {
                 const unsigned lds_a = dma_base + (unsigned)(SLOT * STAGE * 4);
@@ -714,6 +741,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
                 dma16(wb, wimg_voff + 4096u, lds_b + 4096u);
                 dma16(wb, wimg_voff + 8192u, lds_b + 8192u);
             }
+            if constexpr (PRO) { issue_s(SLOT); scb += BK; }
             xb += BK;
             wb += B_STAGE;
             if constexpr (MODE == 2) {
@@ -758,6 +786,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 #undef SN_READA
 #undef SN_READB0
 #undef SN_READB1
+#undef SN_READS8
 #undef SN_WAIT_A01
 #undef SN_WAIT_A23B0
 #undef SN_WAIT_B1
