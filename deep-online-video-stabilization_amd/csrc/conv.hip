@@ -102,6 +102,8 @@ static int conv_total_steps(const ConvArgs& a) {
 // ---- measured split-K table ------------------------------------------------------------------------------------
 struct TuneEntry { int M, Cout, K, KH, ring, splitk; };
 #include "conv_tuning_table.h"          // static const TuneEntry g_tuning_builtin[]; generated by tools/tune_splitk.py
+#include "conv_tuning_table_packed.h"   // static const TuneEntry g_tuning_packed[]: the same measurement with the packed split kernels (operand mode 4)
+static int g_tuning_profile = 0;        // 1: plans are made for the packed split kernels (stabnet_conv_tuning_profile)
 static std::vector<TuneEntry> g_tuning_runtime;      // set through stabnet_conv_tuning_table_set (the tuner itself)
 static int g_tuning_use_builtin = -1;
 
@@ -109,6 +111,9 @@ static int tuning_lookup(int M, int Cout, int K, int KH, int ring) {
     for (const TuneEntry& e : g_tuning_runtime)
         if (e.M == M && e.Cout == Cout && e.K == K && e.KH == KH && e.ring == ring) return e.splitk;
     if (g_tuning_use_builtin < 0) g_tuning_use_builtin = env_int("STABNET_CONV_TUNING_TABLE", 1);
+    if (g_tuning_use_builtin && g_tuning_profile == 1)
+        for (const TuneEntry& e : g_tuning_packed)
+            if (e.M == M && e.Cout == Cout && e.K == K && e.KH == KH && e.ring == ring) return e.splitk;
     if (g_tuning_use_builtin)
         for (const TuneEntry& e : g_tuning_builtin)
             if (e.M == M && e.Cout == Cout && e.K == K && e.KH == KH && e.ring == ring) return e.splitk;
@@ -302,6 +307,21 @@ static int launch_ring_packed_mode(const ConvArgs& a, hipStream_t st) {
     SN_LAUNCH_CHECK("conv_ring_f32_kernel<packed>");
     return STABNET_OK;
 }
+// Two K groups inside the workgroup (p.splitk == 2, equal slices): 8 waves, 2 x 60 KiB of ring, one workgroup per CU, no reduce launch.
+static int launch_ring_packed_kg2(const ConvArgs& a, hipStream_t st) {
+    const int cus = device_cus();
+    if (cus <= 0) {
+        stabnet_set_error("conv: cannot read the CU count");
+        return STABNET_ERR_LAUNCH;
+    }
+    const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64);
+    const int grid = (int)std::min<long>(ntiles, usable_cus(cus));
+    if (a.in_scale != nullptr) conv_ring_f32_kernel<0, 4, 2, 1><<<grid, 512, 0, st>>>(a);
+    else if (a.pad == 0) conv_ring_f32_kernel<0, 4, 2, 0><<<grid, 512, 0, st>>>(a);
+    else conv_ring_f32_kernel<1, 4, 2, 0><<<grid, 512, 0, st>>>(a);
+    SN_LAUNCH_CHECK("conv_ring_f32_kernel<packed, KG 2>");
+    return STABNET_OK;
+}
 static int launch_ring_packed(const ConvArgs& a, hipStream_t st) {
     if (a.rowrun) return launch_ring_packed_mode<2>(a, st);
     return a.pad == 0 ? launch_ring_packed_mode<0>(a, st) : launch_ring_packed_mode<1>(a, st);
@@ -476,10 +496,14 @@ int conv_launch(const ConvArgs& a_in, hipStream_t st, Prof* prof, int bf16_opera
                             ring_pro_vectors_ok(a) && (a.splitk == 1 || a.partial != nullptr);
     if (packed_pro) kg = 1;
     const bool packed = (want_packed && ring && kg == 1 && !pro && a.K % 32 == 0) || packed_pro;
+    // a two-way K split runs inside the workgroup (no slabs, no reduce launch)
+    static const int packed_kg2_on = env_int("STABNET_CONV_PACKED_KG2", 1);
+    const bool packed_kg2 = packed && packed_kg2_on && a.splitk == 2 && !a.rowrun && a.steps_per_split * 2 == conv_total_steps(a);
+    if (packed_kg2) kg = 2;
     if (packed) {
         ConvArgs b = a;
         b.w = w_img;
-        rc = launch_ring_packed(b, st);
+        rc = packed_kg2 ? launch_ring_packed_kg2(b, st) : launch_ring_packed(b, st);
     } else if (pro) {
         rc = launch_ring_pro(a, 0, st);
     } else if (kg > 1) {
@@ -668,6 +692,8 @@ void stabnet_conv_tuning_override(int tile, int splitk) {
 /* Tuning hook (tools/tune_splitk.py): split-K of the convolution with GEMM shape (M, Cout, K), filter height KH, on the
  * ring kernel (ring = 1: no input BN prologue) or the register-staged kernel (ring = 0); splitk <= 0 removes the entry,
  * M < 0 clears the table.  Takes effect for plans made afterwards (net_create / conv2d calls).  Not thread-safe. */
+void stabnet_conv_tuning_profile(int profile) { g_tuning_profile = profile == 1 ? 1 : 0; }
+
 void stabnet_conv_tuning_table_set(int M, int Cout, int K, int KH, int ring, int splitk) {
     if (M < 0) { g_tuning_runtime.clear(); return; }
     for (size_t i = 0; i < g_tuning_runtime.size(); ++i) {
@@ -727,6 +753,46 @@ int stabnet_conv2d_fwd_ex(const float* x, const float* w_ohwi, const float* bias
     a.out_scale = out_scale;
     a.out_shift = out_shift;
     return conv_launch(a, (hipStream_t)stream);
+}
+
+/* stabnet_conv2d_fwd_ex through the packed split kernels (include/stabnet_hip.h) */
+size_t stabnet_conv_weight_image_floats(int Cout, int KH, int KW, int Cin) {
+    const int K = KH * KW * Cin;
+    return (Cout > 0 && K > 0 && K % 32 == 0) ? conv_weight_image_floats(Cout, K) : 0;
+}
+
+int stabnet_conv_weight_split_image(const float* w_ohwi, int Cout, int KH, int KW, int Cin, float* w_img, void* stream) {
+    SN_REQUIRE(w_ohwi && w_img, "conv_weight_split_image: null pointer");
+    SN_REQUIRE(Cin % 32 == 0, "conv_weight_split_image: Cin=%d must be a multiple of 32", Cin);
+    return launch_weight_split_image(w_ohwi, Cout, KH * KW * Cin, w_img, (hipStream_t)stream);
+}
+
+int stabnet_conv2d_fwd_packed(const float* x, const float* w_ohwi, const float* w_img, const float* bias, const float* in_scale,
+                              const float* in_shift, const float* residual, int res_H, int res_W, int res_stride,
+                              const float* out_scale, const float* out_shift, float* y, int N, int H, int W, int Cin,
+                              int Cout, int KH, int KW, int stride, int pad, int relu_out, int splitk, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    SN_REQUIRE(x && w_ohwi && w_img && y, "conv2d_fwd_packed: null pointer");
+    SN_REQUIRE((out_scale == nullptr) == (out_shift == nullptr), "conv2d_fwd_packed: out_scale and out_shift go together");
+    ConvArgs a;
+    int rc = fill_args(a, x, w_ohwi, bias, in_scale, in_shift, residual, res_H, res_W, res_stride, y, N, H, W, Cin, Cout,
+                       KH, KW, stride, pad, relu_out);
+    if (rc) return rc;
+    size_t need = conv_plan(a);
+    if (splitk > 0) {                                        // the caller's K split instead of the planned one
+        const int total = conv_total_steps(a);
+        a.steps_per_split = cdiv(total, std::min(splitk, total));
+        a.splitk = cdiv(total, a.steps_per_split);
+        need = a.splitk > 1 ? (size_t)a.splitk * a.M * a.Cout * sizeof(float) : 0;
+    }
+    if (need > workspace_bytes || (need > 0 && workspace == nullptr)) {
+        stabnet_set_error("conv2d_fwd_packed: workspace %zu B < %zu B needed", workspace_bytes, need);
+        return STABNET_ERR_WORKSPACE;
+    }
+    a.partial = static_cast<float*>(workspace);
+    a.out_scale = out_scale;
+    a.out_shift = out_shift;
+    return conv_launch(a, (hipStream_t)stream, nullptr, 4, w_img);
 }
 
 /* conv2 (3x3, pad 1, stride 1 | 2, C -> C channels, C = 64 | 128, no bias) -> folded BN (mid_scale, mid_shift) + ReLU -> conv3

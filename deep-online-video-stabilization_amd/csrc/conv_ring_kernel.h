@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     constexpr int B_STAGE = PK ? 3072 : BN * BK;           // floats
     constexpr int STAGE = BM * BK + B_STAGE;               // floats
     static_assert(!PRO || (MODE == 0 && BF16 != 1), "the fragment prologue exists for the 1x1 fp32 / split kernels");
-    static_assert(!PK || KG == 1, "the packed split kernel has no in-workgroup split-K yet");
+    static_assert(!PK || KG <= 2, "the packed split kernel splits K inside the workgroup two ways at most (60 KiB of ring per group)");
     constexpr int SC_FLOATS = PRO ? 3 * 4 * 64 : 0;        // per group, stage and wave: 32 scales + 32 shifts, behind the rings
     __shared__ __attribute__((aligned(16))) float ring[KG * 3 * STAGE + KG * SC_FLOATS];
 
@@ -489,8 +489,11 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
                 if (remaining > 1) { if constexpr (PRO) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 SN_BARRIER();
-                SN_READS8(((SLOT + 1) % 3) * 1024); SN_READA4(OFF_NEXT); SN_READB0(OFF_NEXT);
             }
+            // UNCONDITIONAL (after the workgroup's last step they fetch stale LDS that nobody uses): a read on only some control-flow
+            // paths makes the compiler merge the pinned registers with their old contents through copies -- copies of registers
+            // whose read is still in flight (seen in the two-group prologue form; tools/check_pinned_regs.py looks for them)
+            SN_READS8(((SLOT + 1) % 3) * 1024); SN_READA4(OFF_NEXT); SN_READB0(OFF_NEXT);
             SN_PMFMA(CP.l, ph1);
             if (feed) { issue_part(SLOT, 0); issue_part(SLOT, 1); SN_SB(); }
             SN_PMFMA(CP.h, pl1);
@@ -650,7 +653,8 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
         if (feed) { issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0); }
         }
         if (tile_done) {
-            if (more) { if constexpr (PK) SN_WAIT_A23B0(0); else if constexpr (PRO) SN_WAIT0P(); else SN_WAIT0(); }   // the next tile's first fragments: landed before the epilogue code
+            if constexpr (PK) { SN_WAIT_A23B0(0); if (!more) SN_BARRIER(); }
+            else if (more) { if constexpr (PRO) SN_WAIT0P(); else SN_WAIT0(); }   // the next tile's first fragments: landed before the epilogue code
             else SN_BARRIER();                             // (otherwise the barrier above already retired slot SLOT)
             SN_STAMP(2);
             if constexpr (KG > 1) {

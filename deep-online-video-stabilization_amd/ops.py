@@ -42,6 +42,29 @@ def conv2d(x, w_ohwi, bias=None, in_scale=None, in_shift=None, residual=None, re
     return y
 
 
+def conv2d_packed(x, w_ohwi, bias=None, in_scale=None, in_shift=None, residual=None, res_stride=1, stride=1, pad=0,
+                  relu_out=False, out_scale=None, out_shift=None, splitk=0):
+    """conv2d on the packed split kernels (stabnet_conv2d_fwd_packed): float32-level results on the bf16 matrix pipe."""
+    x = dev_f32(x, "x")
+    w = dev_f32(w_ohwi, "w")
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, Cw = w.shape
+    assert Cw == Cin, "weight Cin %d != input Cin %d" % (Cw, Cin)
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    y = empty((N, Ho, Wo, Cout), x)
+    L = _lib.lib()
+    img = torch.empty(max(int(L.stabnet_conv_weight_image_floats(Cout, KH, KW, Cin)), 1), dtype=torch.float32, device=x.device)
+    _lib.call("stabnet_conv_weight_split_image", ptr(w), Cout, KH, KW, Cin, ptr(img), stream_ptr(x.device), device=x.device)
+    ws_bytes = max(int(L.stabnet_conv2d_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)), max(splitk, 0) * N * Ho * Wo * Cout * 4)
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=x.device)
+    rH, rW = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)
+    _lib.call("stabnet_conv2d_fwd_packed", ptr(x), ptr(w), ptr(img), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(residual), rH, rW,
+              res_stride, ptr(out_scale), ptr(out_shift), ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, int(relu_out), int(splitk),
+              ptr(ws), ws_bytes, stream_ptr(x.device), device=x.device)
+    return y
+
+
 def conv3x3_conv1x1(x, w2_ohwi, mid_scale, mid_shift, w3_ohwi, bias3=None, residual=None, res_stride=1, stride=1, relu_out=False,
                     out_scale=None, out_shift=None, x_ch0=0, res_ch0=0):
     """The tail of a bottleneck unit as one launch (stabnet_conv3x3_conv1x1_fwd): conv2 3x3 (pad 1, `stride`) -> folded BN + ReLU

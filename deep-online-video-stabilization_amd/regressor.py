@@ -92,9 +92,17 @@ class Regressor:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.StabnetError("Regressor needs a GPU device; there is no CPU fallback")
-        self.plan = NetPlan(N, H, W, cfg, keep_activations)
-        if bf16_operands:              # secondary fast mode (bf16 conv operands, fp32 accumulate); default is exact fp32
-            _lib.call("stabnet_net_set_bf16_operands", self.plan.handle, int(bf16_operands))
+        mode = int(bf16_operands)      # conv operand mode (include/stabnet_hip.h): 0 exact f32 MFMA, 1 bf16 operands, 2 / 3 split, 4 packed split
+        packed_plan = (mode == 4 and not keep_activations)
+        if packed_plan:                # split-K choices measured with the packed split kernels
+            _lib.lib().stabnet_conv_tuning_profile(1)
+        try:
+            self.plan = NetPlan(N, H, W, cfg, keep_activations)
+        finally:
+            if packed_plan:
+                _lib.lib().stabnet_conv_tuning_profile(0)
+        if mode:
+            _lib.call("stabnet_net_set_bf16_operands", self.plan.handle, mode)
         flat = params if isinstance(params, np.ndarray) and params.ndim == 1 else self.plan.pack(params)
         self.params = torch.from_numpy(np.ascontiguousarray(flat)).to(self.device)
         self.fold = torch.empty(int(_lib.lib().stabnet_net_fold_floats(self.plan.handle)), dtype=torch.float32, device=self.device)

@@ -73,6 +73,10 @@ void stabnet_conv_tuning_override(int tile, int splitk);
 /* Tuning hook (tools/tune_splitk.py): measured split-K of one convolution shape; ring = 1 for prologue-free launches.
  * splitk <= 0 removes the entry, M < 0 clears the table.  Applies to plans made afterwards. */
 void stabnet_conv_tuning_table_set(int M, int Cout, int K, int KH, int ring, int splitk);
+/* Which measured split-K table plans made AFTERWARDS use: 0 = the exact-f32-MFMA kernels (default), 1 = the packed split kernels
+ * (operand mode 4 of stabnet_net_set_bf16_operands: two workgroups per CU, two-way K split inside the workgroup).  Set it around
+ * stabnet_net_create() of a plan that will run in mode 4 (stabnet_amd.regressor does). */
+void stabnet_conv_tuning_profile(int profile);
 int stabnet_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, const float* in_scale,
                        const float* in_shift, const float* residual, int res_H, int res_W, int res_stride, float* y,
                        int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu_out,
@@ -85,6 +89,21 @@ int stabnet_conv2d_fwd_ex(const float* x, const float* w_ohwi, const float* bias
                           const float* out_scale, const float* out_shift, float* y, int N, int H, int W, int Cin,
                           int Cout, int KH, int KW, int stride, int pad, int relu_out, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* stabnet_conv2d_fwd_ex on the bf16 matrix pipe with float32-level results ("packed split", operand mode 4 of
+ * stabnet_net_set_bf16_operands; replaces the same slim conv2d calls, s_net_bundle_nobm.py:252-253): every float32 operand is the
+ * exact sum of three bf16 terms, the product is accumulated in float32 from six bf16 x bf16 partial products.  The weights are
+ * split once: stabnet_conv_weight_split_image() writes the fragment-major image (stabnet_conv_weight_image_floats() floats, Cin a
+ * multiple of 32) the kernel reads; w_ohwi must still be passed (geometries the packed kernel does not take -- Cin % 32 != 0,
+ * other tiles -- run stabnet_conv2d_fwd_ex's exact-f32 kernels on it).  splitk > 0 forces the K split (2 with equal halves runs
+ * inside the workgroup, others through `workspace` slabs + a reduce launch); 0 = the planned one.  workspace: at least
+ * max(stabnet_conv2d_workspace_bytes(), splitk * N*Ho*Wo*Cout * 4). */
+size_t stabnet_conv_weight_image_floats(int Cout, int KH, int KW, int Cin);
+int stabnet_conv_weight_split_image(const float* w_ohwi, int Cout, int KH, int KW, int Cin, float* w_img, void* stream);
+int stabnet_conv2d_fwd_packed(const float* x, const float* w_ohwi, const float* w_img, const float* bias, const float* in_scale,
+                              const float* in_shift, const float* residual, int res_H, int res_W, int res_stride,
+                              const float* out_scale, const float* out_shift, float* y, int N, int H, int W, int Cin,
+                              int Cout, int KH, int KW, int stride, int pad, int relu_out, int splitk, void* workspace,
+                              size_t workspace_bytes, void* stream);
 /* The tail of a slim bottleneck_v2 unit as ONE launch (resnet_v2 `bottleneck`, called at s_net_bundle_nobm.py:252-253; what the
  * inference plan runs for the block-1 / block-2 units of a frame): conv2 (3x3, pad 1, stride 1 | 2, C -> C channels, C = 64 | 128,
  * no bias) -> folded batch_norm (mid_scale, mid_shift) + ReLU -> conv3 (1x1, C -> Cout, Cout % C == 0) with conv2d_fwd_ex's
@@ -110,8 +129,16 @@ int stabnet_conv3x3_conv1x1_fwd(const float* x, int x_ld, const float* w2_ohwi, 
  * (conv: un-padded Cin). */
 int stabnet_net_create(void** net, int N, int H, int W, int in_ch, int n_theta, int keep_activations);
 void stabnet_net_destroy(void* net);
-/* SECONDARY fast mode of the inference forward (off by default, never the headline): conv operands
- * rounded to bf16 at fragment-read time (fp32 tensors in memory, fp32 accumulate).  Own, looser parity bar. */
+/* Conv operand mode of the inference forward (tensors are float32 in memory and accumulation is float32 in every mode):
+ *   0  exact f32 MFMA (v_mfma_f32_32x32x2_f32), the default;
+ *   1  SECONDARY reduced-precision mode (never the headline): operands rounded to bf16 at fragment-read
+ *      time.  Own, looser parity bar (3e-3 on theta);
+ *   2 / 3  split operands: every f32 operand is decomposed EXACTLY into three bf16 terms (x = h + m + l) when its fragment is read
+ *      and the f32 product is accumulated as six (3: all nine) bf16 x bf16 partial products on v_mfma_f32_32x32x16_bf16 -- f32-level
+ *      results (theta within 2e-7 of the oracle, like mode 0) on the 16x faster matrix pipe; VALU-bound, slower than mode 0: kept
+ *      as the reference form of mode 4;
+ *   4  packed split: the weights are split once into a fragment-major image inside `fold` (stabnet_net_fold_bn), only the A
+ *      fragments are split at run time (conv_ring_f32_kernel<MODE, 4, KG, PRO>).  Same f32-level parity bar as mode 0. */
 int stabnet_net_set_bf16_operands(void* net, int on);
 int stabnet_net_num_params(const void* net);
 int stabnet_net_param_info(const void* net, int idx, char* name, int name_cap, long* offset, int* kind, int* dims4,

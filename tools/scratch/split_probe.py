@@ -8,6 +8,16 @@ from stabnet_amd.config import Config
 from stabnet_amd.regressor import Regressor
 from stabnet_amd.deploy import StabNetStream
 dev = torch.device("cuda:0")
+import re
+from stabnet_amd import _lib
+tab = os.environ.get("PROBE_TABLE")
+if tab:
+    L = _lib.lib()
+    for m in re.finditer(r"\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},", open(tab).read()):
+        v = [int(x) for x in m.groups()]
+        if v[0] > 0:
+            L.stabnet_conv_tuning_table_set(*v)
+    print("runtime split-K table:", tab)
 modes = [0, 4]
 for (N, H, W) in [(2, 64, 96), (1, 288, 512)]:
     cfg, ocfg = Config(height=H, width=W), O.Config(height=H, width=W)

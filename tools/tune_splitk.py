@@ -18,6 +18,7 @@ ap.add_argument("--gap-us", type=float, default=2.6, help="average launch gap ch
 ap.add_argument("--skip-train", action="store_true")
 ap.add_argument("--skip-infer", action="store_true")
 ap.add_argument("--infer-sizes", default="720x1280", help="comma list of HxW deploy workloads, e.g. 720x1280,1080x1920,288x512,256x256")
+ap.add_argument("--mode", type=int, default=0, help="conv operand mode of the deploy workloads (4: packed split kernels -> conv_tuning_table_packed.h)")
 ap.add_argument("--merge", action="store_true", help="keep the entries of the existing table for shapes not measured in this run")
 a = ap.parse_args()
 L = _lib.lib()
@@ -26,7 +27,7 @@ CANDS = [1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20]
 
 def key_of(name, shp):
     M, N, K, _ = shp
-    if name.startswith("conv_ring_f32_kernel<0, 0, 1, 1>") or name.startswith("conv_ring_f32_kernel<0, 0, 2, 1>"):   # the fragment-prologue forms run the register-staged kernel's plans
+    if name.startswith("conv_ring_f32_kernel<0, 0, 1, 1>") or name.startswith("conv_ring_f32_kernel<0, 0, 2, 1>") or name.startswith("conv_ring_f32_kernel<0, 4, 1, 1>"):   # the fragment-prologue forms run the register-staged kernel's plans
         return (M, N, K, 1, 0)
     if name.startswith("conv_ring_f32_kernel<0"):
         return (M, N, K, 1, 1)
@@ -72,7 +73,7 @@ def run_infer(table):
     cfg = Config(height=H, width=W)
     P = synthetic.make_params(cfg, 0, 0.2)
     clip = torch.from_numpy(synthetic.make_clip(H, W, 4, 1234)).cuda()
-    s = StabNetStream(P, H, W, cfg, streams=1)
+    s = StabNetStream(P, H, W, cfg, streams=1, bf16_operands=a.mode)
     fr = [clip[t:t + 1].contiguous() for t in range(4)]
     s.start(fr[0])
     for i in range(5):
@@ -156,12 +157,19 @@ if not a.skip_train:
             table.setdefault(k, v)
 L.stabnet_conv_tuning_table_set(-1, 0, 0, 0, 0, 0)
 with open(a.out, "w") as f:
-    f.write("// Measured split-K choices {M, Cout, K, KH, ring, splitk}; GENERATED by tools/tune_splitk.py on MI355X -- do not edit.\n")
-    f.write("// Workloads: deploy batch 1 at 1280x720, 1920x1080, 512x288 and 256x256 (BASELINE configs[1], [4], the reference's native\n")
-    f.write("// size, configs[0]); training 8 pairs at 288x512 (forward with BN prologue: ring 0, both towers as one launch where the\n")
-    f.write("// tile allows it, i.e. M of 16 samples; dgrad of the pair: ring 1).\n")
-    f.write("// Per shape: the smallest split within 1 % of the fastest measured one (kernel + reduce launch + launch gap, in-network).\n")
-    f.write("static const TuneEntry g_tuning_builtin[] = {\n")
+    if a.mode == 4:
+        f.write("// Measured split-K choices {M, Cout, K, KH, ring, splitk} for plans that run the packed split kernels (operand mode 4:\n")
+        f.write("// conv_ring_f32_kernel<MODE, 4, KG, PRO>, two workgroups per CU, a two-way split inside the workgroup); GENERATED by\n")
+        f.write("// tools/tune_splitk.py --mode 4 on MI355X -- do not edit.  Shapes not listed fall back to conv_tuning_table.h.\n")
+        f.write("// Per shape: the smallest split within 1 % of the fastest measured one (kernel + reduce launch + launch gap, in-network).\n")
+        f.write("static const TuneEntry g_tuning_packed[] = {\n")
+    else:
+        f.write("// Measured split-K choices {M, Cout, K, KH, ring, splitk}; GENERATED by tools/tune_splitk.py on MI355X -- do not edit.\n")
+        f.write("// Workloads: deploy batch 1 at 1280x720, 1920x1080, 512x288 and 256x256 (BASELINE configs[1], [4], the reference's native\n")
+        f.write("// size, configs[0]); training 8 pairs at 288x512 (forward with BN prologue: ring 0, both towers as one launch where the\n")
+        f.write("// tile allows it, i.e. M of 16 samples; dgrad of the pair: ring 1).\n")
+        f.write("// Per shape: the smallest split within 1 % of the fastest measured one (kernel + reduce launch + launch gap, in-network).\n")
+        f.write("static const TuneEntry g_tuning_builtin[] = {\n")
     for (M, N, K, kh, ring), s in sorted(table.items()):
         f.write("    {%d, %d, %d, %d, %d, %d},\n" % (M, N, K, kh, ring, s))
     f.write("    {0, 0, 0, 0, 0, 0},\n};\n")
