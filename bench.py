@@ -28,6 +28,13 @@ import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
+PEAK_BF16_MFMA_TFLOPS = 2516.6   # v_mfma_f32_32x32x16_bf16: 32 cycles per 32x32x16 on each of 256 CUs x 4 SIMDs at 2.4 GHz (~2.5 PF dense)
+SPLIT_PRODUCTS = 6               # bf16 x bf16 partial products per f32 product in operand mode 4 (conv_kernel.h)
+PEAK_SPLIT_F32_TFLOPS = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS   # f32-equivalent matrix peak of the packed split kernels
+
+
+def is_packed_kernel(name):
+    return name.startswith("conv_ring_f32_kernel<") and name.split(",")[1].strip() == "4"
 
 
 def parse():
@@ -53,6 +60,11 @@ def parse():
     ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the frame eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the SECONDARY bf16-operand line (never the headline)")
+    ap.add_argument("--operand-mode", type=int, default=4, choices=[0, 2, 3, 4],
+                    help="conv operand mode of the frame (include/stabnet_hip.h, stabnet_net_set_bf16_operands): 4 = packed split "
+                         "kernels (float32 operands as exact 3 x bf16 sums on the bf16 matrix pipe, f32 accumulate; f32-level "
+                         "parity, the default), 0 = exact f32 MFMA")
+    ap.add_argument("--no-f32-mfma-leg", action="store_true", help="skip the second figure taken with --operand-mode 0")
     ap.add_argument("--dump-event-raw", default=None, metavar="JSON",
                     help="write {kernel: raw HIP-event average} of the instrumented pass (tools/profile_stamp.py calibrates the "
                          "per-kernel event offsets against rocprofv3 with it)")
@@ -294,9 +306,16 @@ def roofline_from_records(recs, steps):
     n, ms, fl, by = agg[name]
     if fl > 0:
         ach = fl / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_us": 1e3 * ms / n,
-                "algorithmic_flops_per_launch": fl / n, "algorithmic_bytes_per_launch": by / n}
+        # `achieved` counts ALGORITHMIC f32 flops.  An exact-f32-MFMA kernel is priced against the f32 MFMA peak; a packed split
+        # kernel executes six bf16 MFMA flops per algorithmic flop and is priced against the bf16 dense peak / 6
+        packed = is_packed_kernel(name)
+        peak = PEAK_SPLIT_F32_TFLOPS if packed else PEAK_F32_MFMA_TFLOPS
+        roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": None, "avg_launch_us": 1e3 * ms / n,
+                "algorithmic_flops_per_launch": fl / n, "algorithmic_bytes_per_launch": by / n,
+                "peak_basis": ("bf16 dense MFMA peak %.1f TF / %d bf16 partial products per f32 product (operand mode 4)" % (
+                    PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS)) if packed else "f32 MFMA peak (v_mfma_f32_32x32x2_f32)",
+                "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS}
     else:
         ach = by / (ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -496,7 +515,7 @@ def main():
     clip_dev = torch.from_numpy(clip).to(dev)                      # resident in HBM before timing
     frames = [clip_dev[t:t + 1].expand(S, H, W).contiguous() for t in range(args.clip_frames)]
     stream = StabNetStream(P, H, W, cfg, streams=S, device=dev, refine=args.refine, before_ch=args.before_ch,
-                           use_graph=not args.no_graph)
+                           use_graph=not args.no_graph, bf16_operands=args.operand_mode)
     stream.start(frames[0])
 
     def barrier():
@@ -559,13 +578,39 @@ def main():
                 roof_warp["kernel"] = "warp_sample_kernel<1>"
         annotate_roofline(roof, ktab, knote, prof)
 
+    f32leg = None
+    if rank == 0 and args.operand_mode != 0 and not args.no_f32_mfma_leg:
+        # the same frames on the exact f32 MFMA kernels (operand mode 0: the headline of rounds 1-3), and what separates the two
+        # modes on ONE frame from identical ring state
+        s0 = StabNetStream(P, H, W, cfg, streams=S, device=dev, refine=args.refine, use_graph=not args.no_graph, bf16_operands=0)
+        s0.start(frames[0])
+        s0.frames_ring.copy_(stream.frames_ring); s0.masks_ring.copy_(stream.masks_ring); s0.head_dev.copy_(stream.head_dev)
+        tt = t
+        for _ in range(max(3, args.warmup // 2)):
+            s0.step(frames[tt % args.clip_frames]); tt += 1
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            s0.step(frames[tt % args.clip_frames]); tt += 1
+        torch.cuda.synchronize()
+        el0 = time.perf_counter() - t2
+        s0.frames_ring.copy_(stream.frames_ring); s0.masks_ring.copy_(stream.masks_ring); s0.head_dev.copy_(stream.head_dev)
+        a = stream.step(frames[t % args.clip_frames])["theta"].clone()
+        stream.frames_ring.copy_(s0.frames_ring); stream.masks_ring.copy_(s0.masks_ring); stream.head_dev.copy_(s0.head_dev)
+        b = s0.step(frames[t % args.clip_frames])["theta"].clone()
+        f32leg = {"label": "the same frames with --operand-mode 0: exact f32 MFMA kernels (v_mfma_f32_32x32x2_f32)",
+                  "value": args.steps * S / el0, "unit": "frames/s", "ms_per_step": 1e3 * el0 / args.steps,
+                  "whole_frame_tflops": plan_flops / (el0 / args.steps) / 1e12,
+                  "whole_frame_frac_of_f32_mfma_peak": plan_flops / (el0 / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                  "theta_max_abs_dev_headline_vs_this": float((a - b).abs().max().item()), "theta_scale": float(b.abs().max().item())}
+        del s0
     bf16 = None
     if rank == 0 and not args.no_bf16_leg:
         # SECONDARY, labelled: the same frames with the conv operands rounded to bf16 at fragment-read time (fp32 tensors,
         # fp32 accumulate).  Reported beside the fp32 headline with the deviation it costs; `value` stays the fp32 figure.
         th32 = stream.theta.clone()
         s16 = StabNetStream(P, H, W, cfg, streams=S, device=dev, refine=args.refine, use_graph=not args.no_graph,
-                            bf16_operands=True)
+                            bf16_operands=1)
         s16.start(frames[0])
         s16.frames_ring.copy_(stream.frames_ring); s16.masks_ring.copy_(stream.masks_ring); s16.head_dev.copy_(stream.head_dev)
         tt = t
@@ -585,7 +630,7 @@ def main():
         bf16 = {"label": "SECONDARY: bf16 conv operands (rounded at fragment-read time), fp32 tensors + fp32 accumulate; "
                          "not the reference's precision, never the headline",
                 "value": args.steps * S / el16, "unit": "frames/s", "ms_per_step": 1e3 * el16 / args.steps,
-                "theta_max_abs_dev_vs_fp32": float((a - b).abs().max().item()), "theta_scale": float(a.abs().max().item())}
+                "theta_max_abs_dev_vs_headline": float((a - b).abs().max().item()), "theta_scale": float(a.abs().max().item())}
         del s16, th32
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -606,13 +651,17 @@ def main():
                       "stabilized frames/sec (%dx%d)" % (W, H),
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.operand_mode == 0 else "f32 (conv operands as exact sums of 3 bf16 terms, %d bf16 partial products per "
+                     "product on v_mfma_f32_32x32x16_bf16, f32 accumulate: f32-level results, tests/test_operand_mode4_gpu.py)" % (
+                         9 if args.operand_mode == 3 else 6),
+            "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: v2_93 net, %dx%d, %d stream(s)/GPU, batch=1 per stream, "
                                    "13-ch stack from a 32-deep ring (lags 1,2,4,8,16,32; --before-ch %d ignored as in "
                                    "the reference), ResNet-v2-50 regressor + 4x4 multi-grid warp + feedback; one "
                                    "independent stream set per GPU (replicas only)" % (W, H, S, args.before_ch),
                        "height": H, "width": W, "streams_per_gpu": S, "refine": args.refine,
                        "backbone_gflop_per_frame": plan_flops / 1e9 / S,
+                       "operand_mode": args.operand_mode,
                        "launches_per_frame": frame_launches + 1, "hip_graph": bool(graph_used)},   # + the frame copy into the graph's input
             "per_gpu_fps": fps / world, "checksum": checksum,
             # BASELINE.json words the metric per GPU; `value` is the whole-job aggregate the bench contract asks for and
@@ -627,15 +676,21 @@ def main():
             line["instrumented_ms_per_step"] = prof_ms
             line["roofline"]["idle_event_pair_us"] = 1e3 * prof.idle_pair_ms
             line["roofline"]["whole_frame_tflops"] = plan_flops / (el / args.steps) / 1e12
+            # the frame's algorithmic f32 flops per second against the f32 MFMA peak (comparable across rounds and modes; a packed
+            # split frame may exceed what f32 MFMA instructions could do) and, in mode 4, against the split kernels' own peak
             line["roofline"]["whole_frame_frac"] = line["roofline"]["whole_frame_tflops"] / PEAK_F32_MFMA_TFLOPS
+            if args.operand_mode == 4:
+                line["roofline"]["whole_frame_frac_of_split_peak"] = line["roofline"]["whole_frame_tflops"] / PEAK_SPLIT_F32_TFLOPS
         if peaks is not None:
             line["empirical_peaks"] = peaks
-            if roof is not None and roof.get("bound") == "mfma":
+            if roof is not None and roof.get("bound") == "mfma" and not is_packed_kernel(roof["kernel"]):   # (the probe is an f32 MFMA chain)
                 line["roofline"]["frac_of_empirical_peak"] = roof["achieved"] / peaks["mfma_f32_tflops"]
             if roof_warp is not None:
                 line["roofline_warp"]["frac_of_empirical_peak"] = roof_warp["achieved"] / peaks["hbm_copy_gbps"]
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        if f32leg is not None:
+            line["f32_mfma_mode"] = f32leg
         if bf16 is not None:
             line["secondary_bf16_operands"] = bf16
         if train is not None:

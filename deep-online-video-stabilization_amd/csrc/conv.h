@@ -54,7 +54,7 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof = nullptr, int bf1
 size_t conv_weight_image_floats(int Cout, int K);
 int launch_weight_split_image(const float* w, int Cout, int K, float* img, hipStream_t st);
 // 1 if that launch is followed by a split-K reduce launch (0: no split, or the split runs inside the workgroups)
-int conv_reduce_launches(const ConvArgs& a);
+int conv_reduce_launches(const ConvArgs& a, int operand_mode = 0);      // (operand_mode 4: as conv_launch() with a weight image decides)
 
 // The two siamese towers of a training step as ONE launch (forward convolutions, conv_kernel.h).  `a` describes the pair as one
 // batch of 2N samples whose first N live where a.x / a.y / a.residual / a.in_scale / a.in_shift point; tiles of rows >= m_tower

@@ -423,12 +423,22 @@ static int launch_ring_pro(ConvArgs a, long delta, hipStream_t st) {
 
 // 1 if conv_launch() of this (planned) convolution is followed by a split-K reduce launch (plan-time view: the prologue is known
 // from in_scale_expected)
-int conv_reduce_launches(const ConvArgs& a) {
+int conv_reduce_launches(const ConvArgs& a, int operand_mode) {
     if (a.splitk < 2) return 0;
     int splitk_unused = 1;
     const int t = pick_tile(a, splitk_unused);
-    const bool ring = ring_eligible(a, t, a.in_scale_expected != 0);
-    return (t == T64x64 && conv_kgroups(a, ring, a.in_scale_expected != 0) > 1) ? 0 : 1;
+    const bool pro = a.in_scale_expected != 0;
+    const bool ring = ring_eligible(a, t, pro);
+    if (operand_mode == 4 && t == T64x64 && a.K % 32 == 0 && conv_bk(a) == 32) {
+        // conv_launch() with a weight image: the packed split kernel takes ring launches and the prologue-carrying 1x1 layers; only a
+        // two-way split with equal halves runs inside the workgroup
+        static const int kg2_on = env_int("STABNET_CONV_PACKED_KG2", 1), pro_on = env_int("STABNET_CONV_PACKED_PRO", 1),
+                         kg3_on = env_int("STABNET_CONV_PACKED_KG3", 1);
+        const int kgf = conv_kgroups(a, ring, pro);
+        const bool takes = (ring && (kgf == 1 || (kgf == 3 && kg3_on))) || (!ring && pro && pro_on && ring_pro_geometry(a, true));
+        if (takes) return (kg2_on && a.splitk == 2 && !a.rowrun && a.steps_per_split * 2 == conv_total_steps(a)) ? 0 : 1;
+    }
+    return (t == T64x64 && conv_kgroups(a, ring, pro) > 1) ? 0 : 1;
 }
 
 // ---- pre-split weight image (conv.h) -----------------------------------------------------------------------------------

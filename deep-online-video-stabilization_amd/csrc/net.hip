@@ -790,7 +790,8 @@ int stabnet_net_num_launches(const void* netp) {
     // (shortened head: GAP partials + fc_1 = 2 launches, fc_2, fc_3, output layer [+ mesh] = 3; else 2 + 4 x fc_launches)
     for (const Step& s : net->steps) {
         if (s.kind == S_CONV_B2B && net->bf16_operands) n += 2 + conv_reduce_launches(s.conv) + conv_reduce_launches(s.conv_b);   // runs as two launches there
-        else n += (s.kind == S_CONV) ? 1 + conv_reduce_launches(s.conv) : (s.kind == S_FC ? fc_launches(s.M) : (s.kind == S_GAP ? 2 : 1));
+        else n += (s.kind == S_CONV) ? 1 + conv_reduce_launches(s.conv, (net->bf16_operands == 4 && s.wimg_off >= 0) ? 4 : 0)
+                                     : (s.kind == S_FC ? fc_launches(s.M) : (s.kind == S_GAP ? 2 : 1));
     }
     if (head_fused_supported(net->N, net->t_last.C, net->fc_dims)) n -= 1 /* gap_finalize */ + (fc_launches(net->N) - 1) * 2;
     return n;

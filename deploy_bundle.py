@@ -50,6 +50,10 @@ def build_parser():
     p.add_argument('--pipeline', action='store_true',
                    help='overlap upload / frame / download of neighbouring frames on three HIP streams (stabnet_amd.deploy.ClipPipeline); '
                         'same output bytes, fps is then the host-to-host rate of the whole loop')
+    p.add_argument('--operand-mode', type=int, default=4, choices=[0, 1, 2, 3, 4],
+                   help='conv operand mode of the regressor (include/stabnet_hip.h): 4 = packed split kernels -- float32 operands as exact '
+                        'sums of three bf16 terms on the bf16 matrix pipe, float32 accumulation, float32-level results (default); '
+                        '0 = exact f32 MFMA; 1 = bf16 operands (reduced precision)')
     return p
 
 
@@ -182,7 +186,7 @@ def main():
     dev = torch.device(args.device)
     torch.cuda.set_device(dev)
     stream = StabNetStream(params, H, W, cfg, streams=1, device=dev, refine=args.refine, before_ch=args.before_ch,
-                           use_graph=True)            # one frame = 75 fixed-argument launches: captured once, replayed per frame
+                           use_graph=True, bf16_operands=args.operand_mode)   # one frame = fixed-argument launches: captured once, replayed per frame
     stream.track_black()            # all_black += round(black) inside every refine pass (deploy_bundle.py:234,291), on the device
 
     clips = []
