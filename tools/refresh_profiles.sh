@@ -46,7 +46,9 @@ python bench.py --height 1080 --width 1920 --no-cpu-baseline --no-train-leg --no
 # multi-GPU readiness on ONE GPU: the same training step through a one-rank RCCL group (5 collectives + stream joins per step), next to
 # the no-group run above on the same box
 STABNET_FORCE_COMM=1 python bench.py --mode train --no-roofline 2> $O/train_rccl.err | grep '^{' > $P/${ROUND}_bench_train_1rank_rccl.json || true
-python tools/layer_table.py > $P/${ROUND}_layers_720p.txt 2> $O/layers.err || true
+python tools/layer_table.py --mode 4 > $P/${ROUND}_layers_720p.txt 2> $O/layers.err || true                      # the default operand mode of bench.py
+python tools/layer_table.py --mode 0 > $P/${ROUND}_layers_720p_f32_mfma.txt 2> $O/layers_f32.err || true
 python tools/layer_table.py --bf16 > $P/${ROUND}_layers_720p_bf16_operands.txt 2> $O/layers_bf16.err || true
+python tools/check_pinned_regs.py > $P/${ROUND}_pinned_regs_check.txt 2>&1 || true
 bash tools/capacity_sweep.sh > $P/${ROUND}_capacity_sweep.txt 2> $O/capacity.err || true
 ls -la $P
