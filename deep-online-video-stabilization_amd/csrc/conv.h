@@ -53,6 +53,11 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof = nullptr, int bf1
 // k = 32 step + 16 group + 8 (e >> 2) + 4 g + (e & 3) -- the k order of the ring kernel's A fragments.
 size_t conv_weight_image_floats(int Cout, int K);
 int launch_weight_split_image(const float* w, int Cout, int K, float* img, hipStream_t st);
+// The images of several weight matrices by ONE launch (the training step re-splits its dgrad weights once per step): matrix i is
+// w_base[w_off[i] ...] as [Cout[i]][K[i]], its image goes to img_base[img_off[i] ...]; tprefix = running thread counts.
+struct WeightImageTable { long w_off[64], img_off[64], tprefix[65]; int Cout[64], K[64]; int n; };
+void weight_image_table_add(WeightImageTable& t, long w_off, long img_off, int Cout, int K);
+int launch_weight_split_images(const float* w_base, float* img_base, const WeightImageTable& t, hipStream_t st);
 // 1 if that launch is followed by a split-K reduce launch (0: no split, or the split runs inside the workgroups)
 int conv_reduce_launches(const ConvArgs& a, int operand_mode = 0);      // (operand_mode 4: as conv_launch() with a weight image decides)
 

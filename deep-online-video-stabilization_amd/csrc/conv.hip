@@ -444,12 +444,9 @@ int conv_reduce_launches(const ConvArgs& a, int operand_mode) {
 // ---- pre-split weight image (conv.h) -----------------------------------------------------------------------------------
 size_t conv_weight_image_floats(int Cout, int K) { return (size_t)cdiv(Cout, 64) * (size_t)(K / 32) * 3072; }
 
-__global__ __launch_bounds__(256) void weight_split_image_kernel(const float* __restrict__ w, int Cout, int K, uint4* __restrict__ img) {
-    // one thread per (N tile, K step, wave column, k group, lane): 8 weights -> three 16-byte plane entries
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+// one thread per (N tile, K step, wave column, k group, lane): 8 weights -> three 16-byte plane entries
+__device__ __forceinline__ void weight_split_image_thread(const float* __restrict__ w, int Cout, int K, uint4* __restrict__ img, long i) {
     const int steps = K / 32;
-    const long total = (long)((Cout + 63) / 64) * steps * 256;
-    if (i >= total) return;
     const int lane = (int)(i & 63), j = (int)((i >> 6) & 1), wn = (int)((i >> 7) & 1);
     const long ts = i >> 8;                                  // nt * steps + ks
     const int ks = (int)(ts % steps), nt = (int)(ts / steps);
@@ -465,6 +462,35 @@ __global__ __launch_bounds__(256) void weight_split_image_kernel(const float* __
     out[0] = __builtin_bit_cast(uint4, SN_CAT8(a.h, b.h));
     out[2 * 64] = __builtin_bit_cast(uint4, SN_CAT8(a.m, b.m));
     out[4 * 64] = __builtin_bit_cast(uint4, SN_CAT8(a.l, b.l));
+}
+
+__global__ __launch_bounds__(256) void weight_split_image_kernel(const float* __restrict__ w, int Cout, int K, uint4* __restrict__ img) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)((Cout + 63) / 64) * (K / 32) * 256) return;
+    weight_split_image_thread(w, Cout, K, img, i);
+}
+
+__global__ __launch_bounds__(256) void weight_split_images_kernel(const float* __restrict__ w_base, float* __restrict__ img_base, const WeightImageTable t) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= t.tprefix[t.n]) return;
+    int e = 0;
+    while (i >= t.tprefix[e + 1]) ++e;                       // (every matrix covers whole 256-thread blocks: uniform per block)
+    weight_split_image_thread(w_base + t.w_off[e], t.Cout[e], t.K[e], reinterpret_cast<uint4*>(img_base + t.img_off[e]), i - t.tprefix[e]);
+}
+
+void weight_image_table_add(WeightImageTable& t, long w_off, long img_off, int Cout, int K) {
+    if (t.n == 0) t.tprefix[0] = 0;
+    t.w_off[t.n] = w_off; t.img_off[t.n] = img_off; t.Cout[t.n] = Cout; t.K[t.n] = K;
+    t.tprefix[t.n + 1] = t.tprefix[t.n] + (long)cdiv(Cout, 64) * (K / 32) * 256;
+    ++t.n;
+}
+
+int launch_weight_split_images(const float* w_base, float* img_base, const WeightImageTable& t, hipStream_t st) {
+    if (t.n == 0) return STABNET_OK;
+    SN_REQUIRE(w_base && img_base && t.n <= 64, "weight images: bad table");
+    weight_split_images_kernel<<<(unsigned)(t.tprefix[t.n] >> 8), 256, 0, st>>>(w_base, img_base, t);
+    SN_LAUNCH_CHECK("weight_split_images_kernel");
+    return STABNET_OK;
 }
 
 int launch_weight_split_image(const float* w, int Cout, int K, float* img, hipStream_t st) {

@@ -672,7 +672,7 @@ int pack_dgrad_weights(const float* w, float* wt, int Cout, int KH, int KW, int 
 // re-packed weights wt [Cin][KH][KW][Cout].  residual (optional, same shape as dX) is added (gradient accumulation).
 int dgrad_launch(const float* dy, const float* wt, float* dx, const float* residual, int N, int H, int W, int Cin,
                  int Cout, int KH, int KW, int stride, int pad, float* splitk_ws, size_t splitk_bytes, hipStream_t st,
-                 Prof* prof) {
+                 Prof* prof, const float* wt_img) {
     ConvArgs a{};
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     a.x = dy; a.w = wt; a.y = dx; a.residual = residual;
@@ -686,7 +686,7 @@ int dgrad_launch(const float* dy, const float* wt, float* dx, const float* resid
         return STABNET_ERR_WORKSPACE;
     }
     a.partial = splitk_ws;
-    return conv_launch(a, st, prof);
+    return conv_launch(a, st, prof, wt_img != nullptr ? 4 : 0, wt_img);
 }
 
 extern "C" {

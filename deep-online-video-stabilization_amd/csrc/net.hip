@@ -117,6 +117,10 @@ struct Net {
     size_t merge_floats = 0;
     size_t wimg_floats = 0;                       // inference plans: pre-split weight images of every convolution (conv.h), behind the merge vectors
     PackTable packs{};                            // dgrad weight re-pack of every unit conv (training)
+    int train_split = 0;                          // training plans: dgrad through the packed split kernels (stabnet_net_set_bf16_operands(net, 4))
+    WeightImageTable dimg{};                      // ... pre-split images of the re-packed dgrad weights, one launch per step
+    long dimg_of_pack[56];                        // image offset of pack entry i (-1: K not a multiple of 32)
+    size_t dimg_floats = 0;
     long pack_w3[16] = {0}, pack_w2[16] = {0}, pack_w1[16] = {0}, pack_sc[16] = {0};   // wt offsets per unit                     // re-laid-out stem weights [64][7][roundup(7*in_ch, 32)] behind the folded BN
     std::vector<UnitInfo> units;
     std::vector<BnInfo> bns;
@@ -486,6 +490,16 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
             net->pack_w1[ui] = add(u.w1, u.dbn, 1, u.cin);
             net->pack_sc[ui] = u.proj ? add(u.w_sc, u.depth, 1, u.cin) : -1;
         }
+        // images of the re-packed dgrad weights: entry i is wt[prefix[i] ...] = [Cin][K*K*Cout] (the dgrad's output channels x its K)
+        net->dimg.n = 0;
+        for (int i = 0; i < t.n; ++i) {
+            const int Kd = t.d[i].K * t.d[i].K * t.d[i].Cout;
+            net->dimg_of_pack[i] = -1;
+            if (Kd % 32 != 0 || net->dimg.n >= 64) continue;
+            net->dimg_of_pack[i] = (long)net->dimg_floats;
+            weight_image_table_add(net->dimg, t.prefix[i], (long)net->dimg_floats, t.d[i].Cin, Kd);
+            net->dimg_floats += conv_weight_image_floats(t.d[i].Cin, Kd);
+        }
     }
     if (net->keep_all) {   // the lockstep forward launches a conv ONCE for both towers where the kernel allows it
         for (Step& st_ : net->steps) {
@@ -750,7 +764,13 @@ void stabnet_net_destroy(void* net) { delete static_cast<Net*>(net); }
 int stabnet_net_set_bf16_operands(void* netp, int on) {
     Net* net = static_cast<Net*>(netp);
     SN_REQUIRE(net != nullptr, "set_bf16_operands: null net");
-    SN_REQUIRE(!net->keep_all || !on, "set_bf16_operands: inference plans only (training stays fp32)");
+    if (net->keep_all) {
+        // training plans: mode 4 = the dgrad launches read a pre-split image of the re-packed weights (written once per step); the
+        // reduced-precision and read-time split modes do not exist for training.  Call it before stabnet_net_train_workspace_bytes().
+        SN_REQUIRE(on == 0 || on == 4, "set_bf16_operands: inference plans only (training stays fp32; mode 4 = packed split dgrad)");
+        net->train_split = on == 4 ? 1 : 0;
+        return STABNET_OK;
+    }
     net->bf16_operands = (on >= 1 && on <= 4) ? on : 0;     // 1: bf16 operands; 2 / 3: split operands (conv_kernel.h sn_split3)
     return STABNET_OK;
 }
@@ -975,7 +995,7 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
 // train_bundle_nobm.py:155-160).  The plan must have been created with keep_activations = 1.
 // =========================================================================================================
 struct TrainLayout {
-    size_t bn_scale, bn_shift, bn_mean, bn_invstd, GA, GB, T1, T2, T3, fcg0, fcg1, partial, fcpart, coef, wt, argmax, splitk, slabs, total;
+    size_t bn_scale, bn_shift, bn_mean, bn_invstd, GA, GB, T1, T2, T3, fcg0, fcg1, partial, fcpart, coef, wt, wt_img, argmax, splitk, slabs, total;
     size_t fcx[4];                  // FC head inputs of the PAIR ([2N, dims[k]], tower 1's rows behind tower 0's), in tower 0's workspace
     size_t fcpart_floats;
     size_t splitk_bytes, slab_floats;
@@ -1034,6 +1054,7 @@ static TrainLayout train_layout(const Net* net) {
     L.fcpart = take(L.fcpart_floats);
     L.coef = take(3 * std::max<size_t>(net->max_c, 2048));
     L.wt = take((size_t)net->packs.prefix[net->packs.n]);
+    L.wt_img = take(net->train_split ? net->dimg_floats : 0);
     L.argmax = take((net->t_pool.size + 3) / 4);              // one byte per pooled element
     size_t sk = net->splitk_bytes;
     for (const UnitInfo& u : net->units) {
@@ -1231,12 +1252,17 @@ static int run_backward_stage(const Net* net, const float* params, int T, const 
     // dgrad of both towers: ONE launch over the [T*N, ...] pair (dy, dx, residual are pair bases)
     auto dgrad = [&](const float* dy, long pack_off, float* dx, const float* res, int H, int W, int Cin, int Cout, int K, int stride,
                      int pad) -> int {
-        return dgrad_launch(dy, wt + pack_off, dx, res, T * N, H, W, Cin, Cout, K, K, stride, pad, splitk, L.splitk_bytes, st, prof);
+        const float* img = nullptr;
+        if (net->train_split)
+            for (int i = 0; i < net->packs.n; ++i)
+                if (net->packs.prefix[i] == pack_off && net->dimg_of_pack[i] >= 0) img = ws[0] + L.wt_img + net->dimg_of_pack[i];
+        return dgrad_launch(dy, wt + pack_off, dx, res, T * N, H, W, Cin, Cout, K, K, stride, pad, splitk, L.splitk_bytes, st, prof, img);
     };
     auto none = [&](int) -> const float* { return nullptr; };
 
     if (stage == 0) {
         if ((rc = pack_dgrad_weights_all(params, wt, net->packs, st)) != 0) return rc;
+        if (net->train_split && (rc = launch_weight_split_images(wt, ws[0] + L.wt_img, net->dimg, st)) != 0) return rc;
         // ---- FC head (resnet.py:44-56, s_net_bundle_nobm.py:256-259) on the pair: the output layer per tower (d_theta are the
         // caller's buffers; dW += in tower order), fc_3..1 and the reduce_mean backward as ONE launch over [T*N, ...]
         const TensorRef& last = net->t_last;

@@ -85,4 +85,4 @@ struct PackTable { PackDesc d[56]; long prefix[57]; int n; };
 int pack_dgrad_weights_all(const float* params, float* wt, const PackTable& t, hipStream_t st);
 int dgrad_launch(const float* dy, const float* wt, float* dx, const float* residual, int N, int H, int W, int Cin,
                  int Cout, int KH, int KW, int stride, int pad, float* splitk_ws, size_t splitk_bytes, hipStream_t st,
-                 Prof* prof);
+                 Prof* prof, const float* wt_img = nullptr /* pre-split image of wt (conv.h): the packed split kernels */);

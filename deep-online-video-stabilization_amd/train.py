@@ -46,7 +46,7 @@ def learning_rate(step: int, cfg: Config) -> float:
 
 class Trainer:
     def __init__(self, params, N: int, H: int, W: int, cfg: Config = v2_93, device="cuda:0", process_group=None,
-                 world_size: int = 1, force_comm: bool = False):
+                 world_size: int = 1, force_comm: bool = False, split_operands=None):
         """force_comm: run the communication path (buckets on the communication stream, wait_stream joins) even for a
         one-rank group -- the sum over one rank is the identity, so the step must equal the no-group step bit for bit; that
         is how the RCCL path is exercised on a one-GPU box (tests/test_rccl_gpu.py)."""
@@ -55,6 +55,18 @@ class Trainer:
         if self.device.type != "cuda":
             raise _lib.StabnetError("Trainer needs a GPU device; there is no CPU fallback")
         self.plan = NetPlan(N, H, W, cfg, keep_activations=True)
+        # split_operands: the dgrad launches of the backward run the packed split kernels (float32 operands as exact sums of three
+        # bf16 terms on the bf16 matrix pipe, f32 accumulate: include/stabnet_hip.h, operand mode 4) on an image of the re-packed
+        # weights written once per step.  None = the STABNET_TRAIN_SPLIT environment switch, default OFF: measured at 8 pairs /
+        # 288x512 the converted dgrad launches are 18-24 % faster (49.4 -> 40.7 us, 103.1 -> 78.2 us: -0.61 ms per step) but every
+        # f32-MFMA launch beside them runs 3-6 % slower (the chip is power-limited and the forward / wgrad launches -- 80 % of the
+        # matrix time -- cannot read a weight image or are not converted yet): 528 -> 518 pairs/s.
+        if split_operands is None:
+            import os
+            split_operands = os.environ.get("STABNET_TRAIN_SPLIT", "0") == "1"
+        self.split_operands = bool(split_operands)
+        if self.split_operands:
+            _lib.call("stabnet_net_set_bf16_operands", self.plan.handle, 4)
         flat = params if isinstance(params, np.ndarray) and params.ndim == 1 else self.plan.pack(params)
         dev = self.device
         self.params = torch.from_numpy(np.ascontiguousarray(flat)).to(dev)

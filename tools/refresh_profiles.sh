@@ -13,6 +13,9 @@ R=$PWD
 ROUND=${1:-r04}
 export TMPDIR=/tmp
 O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
+( while true; do date >> $O/heartbeat.txt; sleep 60; done ) &      # (a counter pass at 1080p is silent for minutes: gpurun takes 7 silent minutes for a hang)
+HEARTBEAT=$!
+trap "kill $HEARTBEAT 2>/dev/null" EXIT
 P=$R/gpurun_out/profiles_$ROUND; rm -rf $P; mkdir -p $P
 mkdir -p $R/profiles
 
@@ -30,14 +33,14 @@ workload() {   # tag, stats csv name, out json name, command text, bench args...
 }
 
 workload 720p ${ROUND}_rocprofv3_kernel_stats_bench720p.csv ${ROUND}_kernel_profile_bench720p.json \
-  "bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train-leg --no-bf16-leg (720p, batch 1)" \
-  --steps 100 --warmup 10 --no-cpu-baseline --no-train-leg --no-bf16-leg || exit 1
+  "bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train-leg --no-bf16-leg --no-f32-mfma-leg (720p, batch 1, operand mode 4)" \
+  --steps 100 --warmup 10 --no-cpu-baseline --no-train-leg --no-bf16-leg --no-f32-mfma-leg || exit 1
 workload train ${ROUND}_rocprofv3_kernel_stats_train_b8.csv ${ROUND}_kernel_profile_train_b8.json \
   "bench.py --mode train --steps 10 --warmup 3 (8 pairs, 288x512)" \
   --mode train --steps 10 --warmup 3 || exit 1
 workload 1080p ${ROUND}_rocprofv3_kernel_stats_bench1080p.csv ${ROUND}_kernel_profile_bench1080p.json \
-  "bench.py --height 1080 --width 1920 --steps 100 --warmup 10 --no-cpu-baseline --no-train-leg --no-bf16-leg (1080p, batch 1)" \
-  --height 1080 --width 1920 --steps 100 --warmup 10 --no-cpu-baseline --no-train-leg --no-bf16-leg || exit 1
+  "bench.py --height 1080 --width 1920 --steps 50 --warmup 5 --no-cpu-baseline --no-train-leg --no-bf16-leg --no-f32-mfma-leg (1080p, batch 1, operand mode 4)" \
+  --height 1080 --width 1920 --steps 50 --warmup 5 --no-cpu-baseline --no-train-leg --no-bf16-leg --no-f32-mfma-leg || exit 1
 
 cd $R
 python bench.py > $P/${ROUND}_bench_720p.json 2> $O/bench.err || exit 1
