@@ -556,9 +556,11 @@ int conv_launch(const ConvArgs& a_in, hipStream_t st, Prof* prof, int bf16_opera
         else rc = launch_one<64, 64, 16, 32, 32>(a, st);
     }
     const int mode = (a.up > 1 || a.rowrun) ? 2 : (a.pad == 0 ? 0 : 1);
+    const bool b_has_pro = a.in_scale != nullptr;           // (the packed launchers pick the prologue form from the pointer)
     int kind = PK_KERNEL_CONV_RING + mode + (bf16_operands ? 3 : 0);
     if (packed) {
-        kind = packed_pro ? PK_KERNEL_CONV_PACKED + 3 : PK_KERNEL_CONV_PACKED + mode;
+        kind = packed_kg2 ? (b_has_pro ? PK_KERNEL_CONV_PACKED + 6 : PK_KERNEL_CONV_PACKED + 4 + mode)
+                          : (b_has_pro ? PK_KERNEL_CONV_PACKED + 3 : PK_KERNEL_CONV_PACKED + mode);
     } else if (pro) {
         kind = PK_KERNEL_CONV_KG + 2;
     } else if (kg > 1) {

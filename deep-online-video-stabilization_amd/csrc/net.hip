@@ -729,6 +729,9 @@ const char* stabnet_prof_kind_name(int kind) {
     if (kind == PK_KERNEL_CONV_PACKED + 1) return "conv_ring_f32_kernel<1, 4, 1, 0>";
     if (kind == PK_KERNEL_CONV_PACKED + 2) return "conv_ring_f32_kernel<2, 4, 1, 0>";
     if (kind == PK_KERNEL_CONV_PACKED + 3) return "conv_ring_f32_kernel<0, 4, 1, 1>";
+    if (kind == PK_KERNEL_CONV_PACKED + 4) return "conv_ring_f32_kernel<0, 4, 2, 0>";
+    if (kind == PK_KERNEL_CONV_PACKED + 5) return "conv_ring_f32_kernel<1, 4, 2, 0>";
+    if (kind == PK_KERNEL_CONV_PACKED + 6) return "conv_ring_f32_kernel<0, 4, 2, 1>";
     if (kind == PK_KERNEL_CONV_B2B) return "conv_b2b_f32_kernel<2>";
     if (kind == PK_KERNEL_CONV_B2B + 1) return "conv_b2b_f32_kernel<4>";
     if (kind >= PK_KERNEL_CONV_BASE && kind < PK_KERNEL_CONV_BASE + 72) {

@@ -8,7 +8,7 @@ enum {
     PK_KERNEL_WARP = 6, PK_KERNEL_ASSEMBLE = 7, PK_KERNEL_PUSH = 8, PK_KERNEL_SPLITK_REDUCE = 9, PK_KERNEL_WGRAD = 10, PK_KERNEL_HEAD = 20,
     PK_KERNEL_WGRAD_SAME = 11 /* + 2*K3 + PRO, + 4 with the bias sums (K3 = 0): conv_wgrad_same_f32_kernel<K3, PRO, BIAS> */,
     PK_KERNEL_CONV_PAIR = 80 /* + 2*MODE + (BK==32): conv_igemm_f32_pair_kernel<64, 64, BK, 32, 32, MODE> */, PK_KERNEL_CONV_KG = 84 /* + mode: conv_ring_f32_kernel<MODE, 0, 3, 0>; + 2: conv_ring_f32_kernel<0, 0, 1, 1> (fragment prologue); + 3: <0, 0, 2, 1> */, PK_KERNEL_CONV_RING = 90 /* + mode; + 3 for the bf16-operand variants */,
-    PK_KERNEL_CONV_PACKED = 70 /* + mode: conv_ring_f32_kernel<MODE, 4, 1, 0> (pre-split weight image) */,
+    PK_KERNEL_CONV_PACKED = 70 /* + mode: conv_ring_f32_kernel<MODE, 4, 1, 0> (pre-split weight image); + 3: <0, 4, 1, 1>; + 4 + mode: <MODE, 4, 2, 0>; + 6: <0, 4, 2, 1> */,
     PK_KERNEL_CONV_B2B = 96 /* conv_b2b_f32_kernel<2>; + 1: <4> */,
     PK_KERNEL_CONV_BASE = 100   // + MODE*6 + tile*2 + (BK==32) + 18 if NBUF == 1 + 36 if BF16 (conv_igemm_f32_kernel<..., NBUF, BF16>)
 };

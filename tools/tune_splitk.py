@@ -27,7 +27,7 @@ CANDS = [1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20]
 
 def key_of(name, shp):
     M, N, K, _ = shp
-    if name.startswith("conv_ring_f32_kernel<0, 0, 1, 1>") or name.startswith("conv_ring_f32_kernel<0, 0, 2, 1>") or name.startswith("conv_ring_f32_kernel<0, 4, 1, 1>"):   # the fragment-prologue forms run the register-staged kernel's plans
+    if name.startswith("conv_ring_f32_kernel<0, 0, 1, 1>") or name.startswith("conv_ring_f32_kernel<0, 0, 2, 1>") or name.startswith("conv_ring_f32_kernel<0, 4, 1, 1>") or name.startswith("conv_ring_f32_kernel<0, 4, 2, 1>"):   # the fragment-prologue forms run the register-staged kernel's plans
         return (M, N, K, 1, 0)
     if name.startswith("conv_ring_f32_kernel<0"):
         return (M, N, K, 1, 1)
