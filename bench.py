@@ -515,7 +515,7 @@ def main():
     clip_dev = torch.from_numpy(clip).to(dev)                      # resident in HBM before timing
     frames = [clip_dev[t:t + 1].expand(S, H, W).contiguous() for t in range(args.clip_frames)]
     stream = StabNetStream(P, H, W, cfg, streams=S, device=dev, refine=args.refine, before_ch=args.before_ch,
-                           use_graph=not args.no_graph, bf16_operands=args.operand_mode)
+                           use_graph=not args.no_graph, operand_mode=args.operand_mode)
     stream.start(frames[0])
 
     def barrier():
@@ -582,7 +582,7 @@ def main():
     if rank == 0 and args.operand_mode != 0 and not args.no_f32_mfma_leg:
         # the same frames on the exact f32 MFMA kernels (operand mode 0: the headline of rounds 1-3), and what separates the two
         # modes on ONE frame from identical ring state
-        s0 = StabNetStream(P, H, W, cfg, streams=S, device=dev, refine=args.refine, use_graph=not args.no_graph, bf16_operands=0)
+        s0 = StabNetStream(P, H, W, cfg, streams=S, device=dev, refine=args.refine, use_graph=not args.no_graph, operand_mode=0)
         s0.start(frames[0])
         s0.frames_ring.copy_(stream.frames_ring); s0.masks_ring.copy_(stream.masks_ring); s0.head_dev.copy_(stream.head_dev)
         tt = t

@@ -102,9 +102,11 @@ class StabNetStream:
     ring depth is max(indices[1:])."""
 
     def __init__(self, params, H: int, W: int, cfg: Config = v2_93, streams: int = 1, device="cuda:0", refine: int = 1,
-                 before_ch=None, use_graph: bool = False, bf16_operands: bool = False):
+                 before_ch=None, use_graph: bool = False, bf16_operands=False, operand_mode=None):
+        """operand_mode: conv operand mode of the regressor (regressor.Regressor; 4 = packed split kernels, what bench.py and
+        deploy_bundle.py run; default 0 = exact f32 MFMA); bf16_operands=True is the older spelling of mode 1."""
         self.cfg, self.H, self.W, self.S, self.refine = cfg, H, W, streams, refine
-        self.reg = Regressor(params, streams, H, W, cfg, device, bf16_operands=bf16_operands)
+        self.reg = Regressor(params, streams, H, W, cfg, device, bf16_operands=bf16_operands, operand_mode=operand_mode)
         dev = self.reg.device
         self.lags = [i for i in cfg.indices[1:] if i > 0]
         self.depth = max(self.lags)

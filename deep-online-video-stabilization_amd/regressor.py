@@ -87,12 +87,15 @@ class Regressor:
     """theta = Regressor(params)(x_tensor): resnet_v2_50 -> mean -> FC head in moving-average BN mode."""
 
     def __init__(self, params, N: int, H: int, W: int, cfg: Config = v2_93, device="cuda:0",
-                 keep_activations: bool = False, bf16_operands: bool = False):
+                 keep_activations: bool = False, bf16_operands=False, operand_mode=None):
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.StabnetError("Regressor needs a GPU device; there is no CPU fallback")
-        mode = int(bf16_operands)      # conv operand mode (include/stabnet_hip.h): 0 exact f32 MFMA, 1 bf16 operands, 2 / 3 split, 4 packed split
+        # conv operand mode (include/stabnet_hip.h): 0 exact f32 MFMA (default), 1 bf16 operands (reduced precision), 2 / 3 split at
+        # fragment-read time, 4 packed split (f32-level results on the bf16 matrix pipe).  `bf16_operands=True` is the older spelling of 1.
+        mode = int(operand_mode) if operand_mode is not None else int(bf16_operands)
+        self.operand_mode = mode
         packed_plan = (mode == 4 and not keep_activations)
         if packed_plan:                # split-K choices measured with the packed split kernels
             _lib.lib().stabnet_conv_tuning_profile(1)

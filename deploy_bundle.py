@@ -186,7 +186,7 @@ def main():
     dev = torch.device(args.device)
     torch.cuda.set_device(dev)
     stream = StabNetStream(params, H, W, cfg, streams=1, device=dev, refine=args.refine, before_ch=args.before_ch,
-                           use_graph=True, bf16_operands=args.operand_mode)   # one frame = fixed-argument launches: captured once, replayed per frame
+                           use_graph=True, operand_mode=args.operand_mode)   # one frame = fixed-argument launches: captured once, replayed per frame
     stream.track_black()            # all_black += round(black) inside every refine pass (deploy_bundle.py:234,291), on the device
 
     clips = []

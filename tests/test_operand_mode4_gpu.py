@@ -28,7 +28,7 @@ def test_regressor_mode4_matches_oracle(cuda, N, H, W):
     x, _ = synthetic.make_stack(cfg, N, H, W, seed=3)
     xt = torch.from_numpy(x).to(cuda)
     th0 = Regressor(P, N, H, W, cfg)(xt).cpu().numpy()
-    th4 = Regressor(P, N, H, W, cfg, bf16_operands=4)(xt).cpu().numpy()
+    th4 = Regressor(P, N, H, W, cfg, operand_mode=4)(xt).cpu().numpy()
     ref, _, _ = O.get_resnet(x, P, ocfg)
     d0, d4, d04 = np.abs(th0 - ref).max(), np.abs(th4 - ref).max(), np.abs(th4 - th0).max()
     print("theta max err vs oracle: f32 MFMA %.2e, packed split %.2e; between them %.2e (theta scale %.3f)" % (d0, d4, d04, np.abs(ref).max()))
@@ -45,7 +45,7 @@ def test_mode4_runs_the_packed_kernels(cuda):
     cfg = Config(height=H, width=W)
     P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
     clip = torch.from_numpy(synthetic.make_clip(H, W, 3, seed=1234)).to(cuda)
-    s = StabNetStream(P, H, W, cfg, streams=1, device=cuda, bf16_operands=4)
+    s = StabNetStream(P, H, W, cfg, streams=1, device=cuda, operand_mode=4)
     s.start(clip[0:1])
     prof = Profiler(400)
     s.step(clip[1:2], prof)
@@ -69,7 +69,7 @@ def test_deploy_step_mode4_matches_oracle_at_size(cuda, H, W, frames):
     cfg, ocfg = Config(height=H, width=W), O.Config(height=H, width=W)
     P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
     clip = synthetic.make_clip(H, W, 3, seed=1234)
-    s = StabNetStream(P, H, W, cfg, streams=1, device=cuda, bf16_operands=4)
+    s = StabNetStream(P, H, W, cfg, streams=1, device=cuda, operand_mode=4)
     s.start(torch.from_numpy(clip[0:1]).to(cuda))
     ring = O.DeployRing(clip[0], ocfg)
     for t in frames:
@@ -97,8 +97,8 @@ def test_mode4_graph_replay_equals_eager(cuda):
     cfg = Config(height=H, width=W)
     P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
     clip = torch.from_numpy(synthetic.make_clip(H, W, 40, seed=7)).to(cuda)
-    a = StabNetStream(P, H, W, cfg, streams=1, device=cuda, bf16_operands=4, use_graph=False)
-    b = StabNetStream(P, H, W, cfg, streams=1, device=cuda, bf16_operands=4, use_graph=True)
+    a = StabNetStream(P, H, W, cfg, streams=1, device=cuda, operand_mode=4, use_graph=False)
+    b = StabNetStream(P, H, W, cfg, streams=1, device=cuda, operand_mode=4, use_graph=True)
     a.start(clip[0:1]); b.start(clip[0:1])
     for t in range(1, 40):
         ra = {k: v.clone() for k, v in a.step(clip[t:t + 1]).items()}

@@ -17,7 +17,7 @@ a = ap.parse_args()
 cfg = Config(height=a.height, width=a.width)
 P = synthetic.make_params(cfg, 0, 0.2)
 clip = torch.from_numpy(synthetic.make_clip(a.height, a.width, 4, 1234)).cuda()
-s = StabNetStream(P, a.height, a.width, cfg, streams=a.streams, bf16_operands=(1 if a.bf16 else a.mode))
+s = StabNetStream(P, a.height, a.width, cfg, streams=a.streams, operand_mode=(1 if a.bf16 else a.mode))
 fr = [clip[t:t+1].expand(a.streams, a.height, a.width).contiguous() for t in range(4)]
 s.start(fr[0])
 for i in range(5): s.step(fr[i % 4])

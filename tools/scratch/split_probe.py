@@ -28,7 +28,7 @@ for (N, H, W) in [(2, 64, 96), (1, 288, 512)]:
     ref64 = None
     th = {}
     for m in modes:
-        th[m] = Regressor(P, N, H, W, cfg, bf16_operands=m)(xt).cpu().numpy()
+        th[m] = Regressor(P, N, H, W, cfg, operand_mode=m)(xt).cpu().numpy()
     print("%dx%dx%d theta scale %.3f" % (N, H, W, np.abs(ref).max()))
     for m in modes:
         print("   mode %d: max |theta - oracle| %.3e   max |theta - mode0| %.3e" % (m, np.abs(th[m] - ref).max(), np.abs(th[m] - th[0]).max()))
@@ -39,7 +39,7 @@ cfg = Config(height=H, width=W)
 P = synthetic.make_params(cfg, seed=0, theta_scale=0.2)
 clip = torch.from_numpy(synthetic.make_clip(H, W, 16, seed=1234)).to(dev)
 for m in modes:
-    st = StabNetStream(P, H, W, cfg, streams=1, device=dev, use_graph=True, bf16_operands=m)
+    st = StabNetStream(P, H, W, cfg, streams=1, device=dev, use_graph=True, operand_mode=m)
     st.start(clip[0:1])
     t = 1
     for _ in range(30):

@@ -73,7 +73,7 @@ def run_infer(table):
     cfg = Config(height=H, width=W)
     P = synthetic.make_params(cfg, 0, 0.2)
     clip = torch.from_numpy(synthetic.make_clip(H, W, 4, 1234)).cuda()
-    s = StabNetStream(P, H, W, cfg, streams=1, bf16_operands=a.mode)
+    s = StabNetStream(P, H, W, cfg, streams=1, operand_mode=a.mode)
     fr = [clip[t:t + 1].contiguous() for t in range(4)]
     s.start(fr[0])
     for i in range(5):
