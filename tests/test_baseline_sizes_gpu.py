@@ -73,7 +73,8 @@ def test_deploy_step_matches_oracle_at_size(cuda, H, W, frames):
         assert np.quantile(d, 0.999) < 5e-3, (t, float(d.max()))
 
 
-def test_config1_clip_256_stream_vs_golden(cuda):
+@pytest.mark.parametrize("operand_mode", [0, 4])       # exact f32 MFMA (library default) and the packed split kernels (bench / deploy default)
+def test_config1_clip_256_stream_vs_golden(cuda, operand_mode):
     """configs[0]: the 64-frame 256x256 clip through StabNetStream, against the oracle's restatement of the deploy loop
     (whose trajectory is committed by oracle/make_golden_clip.py).  Three layers of checking:
       (1) per frame, from the ORACLE's ring state (teacher-forced recurrence: the GPU ring is loaded with the oracle's 32
@@ -96,8 +97,8 @@ def test_config1_clip_256_stream_vs_golden(cuda):
     P = synthetic.make_params(cfg, seed=weight_seed, theta_scale=float(g["theta_scale"]))
     clip = synthetic.make_clip(H, W, Tn, seed=clip_seed, margin=64)
     dclip = torch.from_numpy(clip).to(cuda)
-    forced = StabNetStream(P, H, W, cfg, streams=1, device=cuda)
-    free = StabNetStream(P, H, W, cfg, streams=1, device=cuda, use_graph=True)
+    forced = StabNetStream(P, H, W, cfg, streams=1, device=cuda, operand_mode=operand_mode)
+    free = StabNetStream(P, H, W, cfg, streams=1, device=cuda, use_graph=True, operand_mode=operand_mode)
     forced.start(dclip[0:1]); free.start(dclip[0:1])
     ring = O.DeployRing(clip[0], ocfg)
     depth = forced.depth
