@@ -34,7 +34,7 @@ PEAK_SPLIT_F32_TFLOPS = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS   # f32-equivalen
 
 
 def is_packed_kernel(name):
-    return name.startswith("conv_ring_f32_kernel<") and name.split(",")[1].strip() == "4"
+    return name.startswith("conv_ring_f32_kernel<") and name.split(",")[1].strip() in ("4", "5")
 
 
 def parse():

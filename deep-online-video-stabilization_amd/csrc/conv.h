@@ -51,6 +51,7 @@ int conv_launch(const ConvArgs& a, hipStream_t st, Prof* prof = nullptr, int bf1
 // Pre-split weight image of a convolution whose weights are [Cout][K] rows (K % 32 == 0): per (64-channel N tile, 32-deep K step)
 // 3072 floats = [wave column 2][plane h, m, l][k group 2][lane 64][8 bf16]; lane (n = lane & 31, g = lane >> 5), element e holds
 // k = 32 step + 16 group + 8 (e >> 2) + 4 g + (e & 3) -- the k order of the ring kernel's A fragments.
+int conv_packed_variant();              // 4 or 5: the BF16 template value the packed launches run (conv.hip)
 size_t conv_weight_image_floats(int Cout, int K);
 int launch_weight_split_image(const float* w, int Cout, int K, float* img, hipStream_t st);
 // The images of several weight matrices by ONE launch (the training step re-splits its dgrad weights once per step): matrix i is

@@ -285,7 +285,16 @@ static int device_cus() {
     return g_cus;
 }
 
-// The packed split kernel (conv_ring_kernel.h, BF16 = 4): 60 KiB of LDS per workgroup -> two per CU.
+// 4 (default): every wave splits both k groups of its A rows itself.  5 (STABNET_CONV_PACKED_SHARE=1): the two waves over the same A
+// rows split one k group each and exchange the planes through LDS -- half the split VALU, a second barrier per step and an LDS
+// round trip: measured SLOWER (stand-alone 35.0 / 38.4 / 131.7 us against 31.0 / 32.5 / 119.7 us, 627 vs 636 frames/s at 720p; even
+// with the barriers compiled out 33.5 / 35.8 / 122.9 us): the split VALU is not what bounds the packed kernel.  Kept as a switch.
+int conv_packed_variant() {
+    static const int share = env_int("STABNET_CONV_PACKED_SHARE", 0);
+    return share ? 5 : 4;
+}
+
+// The packed split kernel (conv_ring_kernel.h, BF16 = 4 / 5): 60 / 72 KiB of LDS per workgroup -> two per CU.
 template <int MODE>
 static int launch_ring_packed_mode(const ConvArgs& a, hipStream_t st) {
     const int cus = device_cus();
@@ -298,12 +307,14 @@ static int launch_ring_packed_mode(const ConvArgs& a, hipStream_t st) {
     const int grid = (int)std::min<long>(ntiles, (long)per_cu * usable_cus(cus));
     if constexpr (MODE == 0) {
         if (a.in_scale != nullptr) {                          // BN + ReLU prologue on the A fragments (the inference conv1 layers)
-            conv_ring_f32_kernel<0, 4, 1, 1><<<grid, 256, 0, st>>>(a);
+            if (conv_packed_variant() == 5) conv_ring_f32_kernel<0, 5, 1, 1><<<grid, 256, 0, st>>>(a);
+            else conv_ring_f32_kernel<0, 4, 1, 1><<<grid, 256, 0, st>>>(a);
             SN_LAUNCH_CHECK("conv_ring_f32_kernel<packed, PRO>");
             return STABNET_OK;
         }
     }
-    conv_ring_f32_kernel<MODE, 4><<<grid, 256, 0, st>>>(a);
+    if (conv_packed_variant() == 5) conv_ring_f32_kernel<MODE, 5><<<grid, 256, 0, st>>>(a);
+    else conv_ring_f32_kernel<MODE, 4><<<grid, 256, 0, st>>>(a);
     SN_LAUNCH_CHECK("conv_ring_f32_kernel<packed>");
     return STABNET_OK;
 }
@@ -316,9 +327,15 @@ static int launch_ring_packed_kg2(const ConvArgs& a, hipStream_t st) {
     }
     const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64);
     const int grid = (int)std::min<long>(ntiles, usable_cus(cus));
-    if (a.in_scale != nullptr) conv_ring_f32_kernel<0, 4, 2, 1><<<grid, 512, 0, st>>>(a);
-    else if (a.pad == 0) conv_ring_f32_kernel<0, 4, 2, 0><<<grid, 512, 0, st>>>(a);
-    else conv_ring_f32_kernel<1, 4, 2, 0><<<grid, 512, 0, st>>>(a);
+    if (conv_packed_variant() == 5) {
+        if (a.in_scale != nullptr) conv_ring_f32_kernel<0, 5, 2, 1><<<grid, 512, 0, st>>>(a);
+        else if (a.pad == 0) conv_ring_f32_kernel<0, 5, 2, 0><<<grid, 512, 0, st>>>(a);
+        else conv_ring_f32_kernel<1, 5, 2, 0><<<grid, 512, 0, st>>>(a);
+    } else {
+        if (a.in_scale != nullptr) conv_ring_f32_kernel<0, 4, 2, 1><<<grid, 512, 0, st>>>(a);
+        else if (a.pad == 0) conv_ring_f32_kernel<0, 4, 2, 0><<<grid, 512, 0, st>>>(a);
+        else conv_ring_f32_kernel<1, 4, 2, 0><<<grid, 512, 0, st>>>(a);
+    }
     SN_LAUNCH_CHECK("conv_ring_f32_kernel<packed, KG 2>");
     return STABNET_OK;
 }

@@ -68,13 +68,21 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     // BF16 == 4 ("packed split"): the B operand is a pre-split, fragment-major IMAGE of the weights (conv.hip,
     // weight_split_image_kernel): per (N tile, K step) 12 KiB = [wave column 2][plane h/m/l 3][k group 2][lane 64][8 bf16], copied
     // linearly by three DMAs per wave and read lane-linearly (conflict-free), so only the A fragments are split at run time.
-    constexpr bool PK = (BF16 == 4);
+    constexpr bool PK = (BF16 >= 4);
+    // BF16 == 5 ("shared split"): the two waves that multiply the same 32 A rows (wn = 0, 1) split ONE k group each and exchange the
+    // planes through LDS (12 KiB per group behind the ring: [wm][k group][plane][lane] 16-B entries, written and read lane-linearly):
+    // 44 split VALU per wave and stage instead of 88 -- the packed kernel is bound by VALU issue (SQ counters), not by
+    // the matrix pipe.  Costs a second barrier per step (plane hand-over) and 3 ds_write + 2 extra ds_read per wave and stage.
+    constexpr bool PS = (BF16 == 5);
+
     constexpr int B_STAGE = PK ? 3072 : BN * BK;           // floats
     constexpr int STAGE = BM * BK + B_STAGE;               // floats
+    constexpr int PLANE_FLOATS = (BF16 == 5) ? 3072 : 0;   // BF16 == 5: plane exchange buffer per K group, behind its ring
+    constexpr int GROUP_FLOATS = 3 * STAGE + PLANE_FLOATS; // one K group's LDS
     static_assert(!PRO || (MODE == 0 && BF16 != 1), "the fragment prologue exists for the 1x1 fp32 / split kernels");
     static_assert(!PK || KG <= 2, "the packed split kernel splits K inside the workgroup two ways at most (60 KiB of ring per group)");
     constexpr int SC_FLOATS = PRO ? 3 * 4 * 64 : 0;        // per group, stage and wave: 32 scales + 32 shifts, behind the rings
-    __shared__ __attribute__((aligned(16))) float ring[KG * 3 * STAGE + KG * SC_FLOATS];
+    __shared__ __attribute__((aligned(16))) float ring[KG * GROUP_FLOATS + KG * SC_FLOATS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (KG > 1) ? ((tid >> 6) & 3) : (tid >> 6);
     const int grp = (KG > 1) ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;      // K group = K slice of this wave
@@ -100,15 +108,15 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     const int run_steps = (MODE == 2) ? p.K / (p.KH * BK) : 0;     // K-steps per filter row (MODE 2)
     const int total_steps = (MODE == 2) ? p.K / BK : p.KH * p.KW * cin_steps;
     const int last_slice_steps = total_steps - (p.splitk - 1) * p.steps_per_split;
-    const unsigned lds_base = (unsigned)(size_t)(sn_lds_ptr_t)ring + (KG > 1 ? (unsigned)grp * (3u * STAGE * 4u) : 0u);   // this group's ring
+    const unsigned lds_base = (unsigned)(size_t)(sn_lds_ptr_t)ring + (KG > 1 ? (unsigned)grp * (unsigned)(GROUP_FLOATS * 4) : 0u);   // this group's ring
 
     // PRO: the pair of towers (see the header comment)
     // (KG > 1 with PRO -- the inference conv1 layers that split K -- is one tower and out_floor is an ordinary floor vector)
     // (the packed split form -- inference conv1 layers -- is one tower as well)
     const long pair_delta = (PRO && KG == 1 && !PK) ? (long)(size_t)p.out_floor : 0L;
     const int m_tower = (PRO && KG == 1 && !PK && pair_delta != 0) ? (p.M >> 1) : 0x7fffffff;
-    const unsigned sc_base = (KG > 1) ? (unsigned)(size_t)(sn_lds_ptr_t)ring + (unsigned)(KG * 3 * STAGE * 4) + (unsigned)grp * (unsigned)(SC_FLOATS * 4)
-                                      : lds_base + 3u * STAGE * 4u;   // [slot][wave][scale 32 | shift 32]
+    const unsigned sc_base = (KG > 1) ? (unsigned)(size_t)(sn_lds_ptr_t)ring + (unsigned)(KG * GROUP_FLOATS * 4) + (unsigned)grp * (unsigned)(SC_FLOATS * 4)
+                                      : lds_base + (unsigned)(GROUP_FLOATS * 4);   // [slot][wave][scale 32 | shift 32]
     // consumer steps of this workgroup (every slice has steps_per_split steps except the last one)
     int remaining = 0;
     for (int t = t_first; t < t_end; t += t_stride) remaining += (t / tiles_mn == p.splitk - 1) ? last_slice_steps : p.steps_per_split;
@@ -379,6 +387,55 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 #define SN_L1(P, c, x0, x1) do { if (!(RING_ABLATE & 32)) P.h.c = sn_split_level(x0, x1); else P.h.c = __builtin_bit_cast(unsigned, x0); } while (0)
 #define SN_L2(P, c, x0, x1) do { if (!(RING_ABLATE & 32)) P.m.c = sn_split_level(x0, x1); else P.m.c = __builtin_bit_cast(unsigned, x1); } while (0)
 #define SN_L3(P, c, x0, x1) do { if (!(RING_ABLATE & 32)) P.l.c = sn_pack_bf16(x0, x1); else P.l.c = __builtin_bit_cast(unsigned, x0); } while (0)
+    // ---- shared split (PS): plane registers (8 bf16 each), the exchange buffer's reads / writes, the own-half reads
+#define SN_QH0 "{v[156:159]}"
+#define SN_QM0 "{v[160:163]}"
+#define SN_QL0 "{v[164:167]}"
+#define SN_QH1 "{v[168:171]}"
+#define SN_QM1 "{v[172:175]}"
+#define SN_QL1 "{v[176:179]}"
+#define SN_READQ()                                                                                                        \
+    do {                                                                                                                  \
+        SN_DS_READ(qh0, SN_QH0, pl_rd0, 0); SN_DS_READ(qm0, SN_QM0, pl_rd0, 1024); SN_DS_READ(ql0, SN_QL0, pl_rd0, 2048);  \
+        SN_DS_READ(qh1, SN_QH1, pl_rd1, 0); SN_DS_READ(qm1, SN_QM1, pl_rd1, 1024); SN_DS_READ(ql1, SN_QL1, pl_rd1, 2048);  \
+    } while (0)
+#define SN_WAIT_Q0B0(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+" SN_QH0(qh0), "+" SN_QM0(qm0), "+" SN_QL0(ql0), "+" SN_PH0(ph0), "+" SN_PM0(pm0), "+" SN_PL0(pl0))
+#define SN_WAIT_Q1B1() asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_QH1(qh1), "+" SN_QM1(qm1), "+" SN_QL1(ql1), "+" SN_PH1(ph1), "+" SN_PM1(pm1), "+" SN_PL1(pl1))
+#define SN_READOWN(off, soff)                                                                                             \
+    do {                                                                                                                  \
+        if constexpr (PRO) {                                                                                              \
+            SN_DS_READ(sc0, SN_RS0, s_own0, soff); SN_DS_READ(sh0, SN_RH0, s_own0, (soff) + 128);                          \
+            SN_DS_READ(sc1, SN_RS1, s_own1, soff); SN_DS_READ(sh1, SN_RH1, s_own1, (soff) + 128);                          \
+        }                                                                                                                 \
+        SN_DS_READ(a0, SN_RA0, a_own0, off); SN_DS_READ(a1, SN_RA1, a_own1, off);                                          \
+    } while (0)
+#define SN_WRITEQ(P)                                                                                                      \
+    do {                                                                                                                  \
+        asm volatile("ds_write_b128 %0, %1" ::"v"(pl_wr), "v"(P.h) : "memory");                                           \
+        asm volatile("ds_write_b128 %0, %1 offset:1024" ::"v"(pl_wr), "v"(P.m) : "memory");                               \
+        asm volatile("ds_write_b128 %0, %1 offset:2048" ::"v"(pl_wr), "v"(P.l) : "memory");                               \
+    } while (0)
+    // shared split, first half of a step: hand-over barrier, both k groups' planes + the B planes of k group 1, six MFMAs
+#define SN_PS_GROUP0(OFF_)                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     /* this wave's plane writes have reached LDS */                \
+    SN_BARRIER();                                          /* ... and so have its partner's */                            \
+    SN_READQ(); SN_READB1(OFF_);                                                                                         \
+    SN_WAIT_Q0B0(6);                                       /* all but the youngest six reads (k group 1 planes, B1) */     \
+    SN_SB();                                                                                                             \
+    SN_PMFMA(ql0, ph0); SN_PMFMA(qh0, pl0); SN_PMFMA(qm0, pm0); SN_PMFMA(qm0, ph0); SN_PMFMA(qh0, pm0); SN_PMFMA(qh0, ph0)
+    // ... last four MFMAs of the second half with the split of this wave's OWN k group of the next stage between them, planes out
+#define SN_PS_GROUP1_TAIL()                                                                                              \
+    SN_WAIT_A01(3);                                        /* own fragments (+ their scales); the next B planes may fly */ \
+    if constexpr (PRO) { SN_PRO(a0, sc0, sh0); SN_PRO(a1, sc1, sh1); }                                                   \
+    float y0 = a0.x, y1 = a0.y, y2 = a0.z, y3 = a0.w, y4 = a1.x, y5 = a1.y, y6 = a1.z, y7 = a1.w;                        \
+    SnPlanes NP;                                                                                                         \
+    SN_SB();                                                                                                             \
+    SN_PMFMA(qm1, pm1); SN_L1(NP, x, y0, y1); SN_L1(NP, y, y2, y3); SN_SB();                                             \
+    SN_PMFMA(qm1, ph1); SN_L1(NP, z, y4, y5); SN_L1(NP, w, y6, y7); SN_SB();                                             \
+    SN_PMFMA(qh1, pm1); SN_L2(NP, x, y0, y1); SN_L2(NP, y, y2, y3); SN_SB();                                             \
+    SN_PMFMA(qh1, ph1); SN_L2(NP, z, y4, y5); SN_L2(NP, w, y6, y7);                                                      \
+    SN_L3(NP, x, y0, y1); SN_L3(NP, y, y2, y3); SN_L3(NP, z, y4, y5); SN_L3(NP, w, y6, y7); SN_SB();                     \
+    SN_WRITEQ(NP); SN_SB()
     // first MFMA group of a packed step (planes AP x B planes of k group 0) with the split of k group 1 (a2, a3 -> CP) in its gaps
 #define SN_PK_GROUP0(OFF_)                                                                                               \
     SN_READB1(OFF_);                                       /* (their registers were the last MFMA's operands) */          \
@@ -446,11 +503,25 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     f32x4 a2, a3;                                          // PK only: A fragments kk = 2, 3
     f32x4 sc2, sh2, sc3, sh3;                              // PK + PRO only
     SnPlanes AP, CP;                                       // PK only: split A planes of k group 0 / 1
+    f32x4 qh0, qm0, ql0, qh1, qm1, ql1;                    // PS only: the planes as read back from the exchange buffer
+    const unsigned pl_base = lds_base + (unsigned)(3 * STAGE * 4);                                     // PS: [wm][k group][plane][lane]
+    const unsigned pl_rd0 = pl_base + (unsigned)((wm * 2 + 0) * 3072 + lane * 16), pl_rd1 = pl_base + (unsigned)((wm * 2 + 1) * 3072 + lane * 16);
+    const unsigned pl_wr = pl_base + (unsigned)((wm * 2 + wn) * 3072 + lane * 16);                      // this wave splits k group wn
+    unsigned a_own0 = 0u, a_own1 = 0u, s_own0 = 0u, s_own1 = 0u;
     const unsigned bimg_frag = lds_base + (unsigned)(4 * BM * BK + wn * 6144 + lane * 16);
     unsigned s_frag[4] = {0u, 0u, 0u, 0u};
     if constexpr (PRO) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) s_frag[kk] = sc_base + (unsigned)(wave * 256 + (8 * kk + 4 * (lane >> 5)) * 4);
+    }
+    if constexpr (PS) {
+        const int ra = wm * 32 + (lane & 31), h = lane >> 5;
+        a_own0 = lds_base + 4 * (ra * BK + (((2 * (2 * wn) + h) ^ ((ra >> 1) & 7)) << 2));
+        a_own1 = lds_base + 4 * (ra * BK + (((2 * (2 * wn + 1) + h) ^ ((ra >> 1) & 7)) << 2));
+        if constexpr (PRO) {
+            s_own0 = sc_base + (unsigned)(wave * 256 + (8 * (2 * wn) + 4 * h) * 4);
+            s_own1 = sc_base + (unsigned)(wave * 256 + (8 * (2 * wn + 1) + 4 * h) * 4);
+        }
     }
     if (RING_ABLATE & 4) { a0 = b0 = a1 = b1 = f32x4{1.f, 2.f, 3.f, 4.f}; }
     issue(0);
@@ -461,7 +532,15 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
     SN_BARRIER();
     SN_STAMP(1);
     issue(2);
-    if constexpr (PK) {
+    if constexpr (PS) {
+        SN_READOWN(0, 0); SN_READB0(0);
+        SN_WAIT_A01(3);
+        if constexpr (PRO) { SN_PRO(a0, sc0, sh0); SN_PRO(a1, sc1, sh1); }
+        const SnPlanes NP0 = sn_split3_pair(a0, a1);
+        SN_SB();
+        SN_WRITEQ(NP0);
+        SN_SB();
+    } else if constexpr (PK) {
         SN_READS8(0); SN_READA4(0); SN_READB0(0);
         SN_WAIT_A01(5);
         if constexpr (PRO) { SN_PRO(a0, sc0, sh0); SN_PRO(a1, sc1, sh1); }
@@ -475,7 +554,28 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
         constexpr int OFF = SLOT * STAGE * 4;
         constexpr int OFF_NEXT = ((SLOT + 1) % 3) * STAGE * 4;
         bool tile_done, more;
-        if constexpr (PK) {
+        if constexpr (PS) {
+            // shared split: at entry the planes of this stage (both k groups, written by this wave and its partner during the
+            // previous step) sit in the exchange buffer and the B planes of k group 0 were read behind the previous barrier
+            constexpr int SOFF_NEXT = ((SLOT + 1) % 3) * 1024;
+            SN_PS_GROUP0(OFF);
+            --remaining;
+            tile_done = (--c_left == 0);
+            more = remaining > 0;
+            const bool feed = more && !tile_done;
+            SN_WAIT_Q1B1();                                    // every fragment of this stage is in registers
+            if (more) {
+                if (remaining > 1) { if constexpr (PRO) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SN_BARRIER();
+            }
+            SN_READOWN(OFF_NEXT, SOFF_NEXT); SN_READB0(OFF_NEXT);            // unconditional (see the packed step below)
+            SN_PMFMA(ql1, ph1);
+            if (feed) { issue_part(SLOT, 0); issue_part(SLOT, 1); SN_SB(); }
+            SN_PMFMA(qh1, pl1);
+            if (feed) { issue_part(SLOT, 2); issue_part(SLOT, 3); SN_SB(); }
+            SN_PS_GROUP1_TAIL();
+        } else if constexpr (PK) {
             // packed split, software-pipelined: at entry AP holds the split planes of k group 0 of this stage (made during the previous
             // step's second MFMA group); a2, a3 (k group 1) and the B planes of k group 0 were read behind the previous barrier.
             // Every split level sits between two MFMAs (sched_barrier pins the order): a 32-cycle MFMA hides about six plain VALU.
@@ -653,7 +753,8 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
         if (feed) { issue_part(SLOT, 3); __builtin_amdgcn_sched_barrier(0); }
         }
         if (tile_done) {
-            if constexpr (PK) { SN_WAIT_A23B0(0); if (!more) SN_BARRIER(); }
+            if constexpr (PS) { asm volatile("s_waitcnt lgkmcnt(0)" : "+" SN_PH0(ph0), "+" SN_PM0(pm0), "+" SN_PL0(pl0)); if (!more) SN_BARRIER(); }
+            else if constexpr (PK) { SN_WAIT_A23B0(0); if (!more) SN_BARRIER(); }
             else if (more) { if constexpr (PRO) SN_WAIT0P(); else SN_WAIT0(); }   // the next tile's first fragments: landed before the epilogue code
             else SN_BARRIER();                             // (otherwise the barrier above already retired slot SLOT)
             SN_STAMP(2);
@@ -676,7 +777,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 #pragma unroll
                     for (int g = 1; g < KG; ++g) {
                         f32x4 t0, t1, t2, t3;
-                        const unsigned src = red + (unsigned)(g * 3 * STAGE * 4);
+                        const unsigned src = red + (unsigned)(g * GROUP_FLOATS * 4);
                         asm volatile("ds_read_b128 %0, %4 offset:0\n\tds_read_b128 %1, %4 offset:1024\n\t"
                                      "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
                                      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(src) : "memory");
@@ -717,13 +818,20 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
         constexpr int OFF = SLOT * STAGE * 4;
         constexpr int OFF_NEXT = ((SLOT + 1) % 3) * STAGE * 4;
         if constexpr (PK) {
-            SN_PK_GROUP0(OFF);
-            --remaining; --c_left; --p_left;
-            SN_WAIT_B1();
+            if constexpr (PS) {
+                SN_PS_GROUP0(OFF);
+                --remaining; --c_left; --p_left;
+                SN_WAIT_Q1B1();
+            } else {
+                SN_PK_GROUP0(OFF);
+                --remaining; --c_left; --p_left;
+                SN_WAIT_B1();
+            }
             if constexpr (PRO) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             SN_BARRIER();
-            SN_READS8(((SLOT + 1) % 3) * 1024); SN_READA4(OFF_NEXT); SN_READB0(OFF_NEXT);
-            SN_PMFMA(CP.l, ph1);
+            if constexpr (PS) { SN_READOWN(OFF_NEXT, ((SLOT + 1) % 3) * 1024); SN_READB0(OFF_NEXT); }
+            else { SN_READS8(((SLOT + 1) % 3) * 1024); SN_READA4(OFF_NEXT); SN_READB0(OFF_NEXT); }
+            if constexpr (PS) SN_PMFMA(ql1, ph1); else SN_PMFMA(CP.l, ph1);
             if (!(RING_ABLATE & 1)) {
                 const unsigned lds_a = dma_base + (unsigned)(SLOT * STAGE * 4);
                 if constexpr (MODE == 1) {
@@ -739,7 +847,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
                 dma16(wb, wimg_voff, lds_a + (unsigned)(BM * BK * 4));
             }
             SN_SB();
-            SN_PMFMA(CP.h, pl1);
+            if constexpr (PS) SN_PMFMA(qh1, pl1); else SN_PMFMA(CP.h, pl1);
             if (!(RING_ABLATE & 1)) {
                 const unsigned lds_b = dma_base + (unsigned)(SLOT * STAGE * 4 + BM * BK * 4);
                 dma16(wb, wimg_voff + 4096u, lds_b + 4096u);
@@ -760,7 +868,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
                 }
             }
             SN_SB();
-            SN_PK_GROUP1_TAIL();
+            if constexpr (PS) { SN_PS_GROUP1_TAIL(); } else { SN_PK_GROUP1_TAIL(); }
         }
     };
     using s0 = std::integral_constant<int, 0>;
@@ -800,6 +908,13 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 #undef SN_L1
 #undef SN_L2
 #undef SN_L3
+#undef SN_READQ
+#undef SN_WAIT_Q0B0
+#undef SN_WAIT_Q1B1
+#undef SN_READOWN
+#undef SN_WRITEQ
+#undef SN_PS_GROUP0
+#undef SN_PS_GROUP1_TAIL
 #undef SN_PK_GROUP0
 #undef SN_PK_GROUP1_TAIL
 }

@@ -725,13 +725,13 @@ const char* stabnet_prof_kind_name(int kind) {
     if (kind == PK_KERNEL_CONV_RING + 3) return "conv_ring_f32_kernel<0, 1, 1, 0>";
     if (kind == PK_KERNEL_CONV_RING + 4) return "conv_ring_f32_kernel<1, 1, 1, 0>";
     if (kind == PK_KERNEL_CONV_RING + 5) return "conv_ring_f32_kernel<2, 1, 1, 0>";
-    if (kind == PK_KERNEL_CONV_PACKED) return "conv_ring_f32_kernel<0, 4, 1, 0>";
-    if (kind == PK_KERNEL_CONV_PACKED + 1) return "conv_ring_f32_kernel<1, 4, 1, 0>";
-    if (kind == PK_KERNEL_CONV_PACKED + 2) return "conv_ring_f32_kernel<2, 4, 1, 0>";
-    if (kind == PK_KERNEL_CONV_PACKED + 3) return "conv_ring_f32_kernel<0, 4, 1, 1>";
-    if (kind == PK_KERNEL_CONV_PACKED + 4) return "conv_ring_f32_kernel<0, 4, 2, 0>";
-    if (kind == PK_KERNEL_CONV_PACKED + 5) return "conv_ring_f32_kernel<1, 4, 2, 0>";
-    if (kind == PK_KERNEL_CONV_PACKED + 6) return "conv_ring_f32_kernel<0, 4, 2, 1>";
+    if (kind >= PK_KERNEL_CONV_PACKED && kind <= PK_KERNEL_CONV_PACKED + 6) {      // conv_ring_f32_kernel<MODE, 4 | 5, KG, PRO>
+        static const int shape[7][3] = {{0, 1, 0}, {1, 1, 0}, {2, 1, 0}, {0, 1, 1}, {0, 2, 0}, {1, 2, 0}, {0, 2, 1}};
+        static thread_local char pbuf[7][48];
+        const int i = kind - PK_KERNEL_CONV_PACKED;
+        snprintf(pbuf[i], sizeof(pbuf[i]), "conv_ring_f32_kernel<%d, %d, %d, %d>", shape[i][0], conv_packed_variant(), shape[i][1], shape[i][2]);
+        return pbuf[i];
+    }
     if (kind == PK_KERNEL_CONV_B2B) return "conv_b2b_f32_kernel<2>";
     if (kind == PK_KERNEL_CONV_B2B + 1) return "conv_b2b_f32_kernel<4>";
     if (kind >= PK_KERNEL_CONV_BASE && kind < PK_KERNEL_CONV_BASE + 72) {

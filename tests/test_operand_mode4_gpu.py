@@ -51,7 +51,7 @@ def test_mode4_runs_the_packed_kernels(cuda):
     s.step(clip[1:2], prof)
     names = [r[0] for r in prof.records()]
     convs = [n for n in names if n.startswith("conv_")]
-    packed = [n for n in convs if n.startswith("conv_ring_f32_kernel<") and n.split(",")[1].strip() == "4"]
+    packed = [n for n in convs if n.startswith("conv_ring_f32_kernel<") and n.split(",")[1].strip() in ("4", "5")]
     flops = {True: 0.0, False: 0.0}
     for r in prof.records():
         if r[0].startswith("conv_") and r[2] > 0:

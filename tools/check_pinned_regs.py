@@ -30,7 +30,7 @@ def check(text, prefixes=("_Z20conv_ring_f32_kernel", "_Z19conv_b2b_f32_kernel")
     bad = []
     for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", text, re.S | re.M):
         name, body = m.group(1), m.group(2)
-        if not name.startswith(prefixes) or re.match(r"_Z20conv_ring_f32_kernelILi\dELi[1-4]E", name):
+        if not name.startswith(prefixes) or re.match(r"_Z20conv_ring_f32_kernelILi\dELi[1-5]E", name):
             continue
         for line in body.splitlines():
             t = line.strip()
