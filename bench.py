@@ -214,6 +214,7 @@ def train_leg(args, dev, dist, rank, world, steps, warmup, with_prof):
 PMC_FILE = os.path.join("profiles", "r04_kernel_profile_bench720p.json")
 PMC_FILE_TRAIN = os.path.join("profiles", "r04_kernel_profile_train_b8.json")
 PMC_FILE_1080P = os.path.join("profiles", "r04_kernel_profile_bench1080p.json")       # BASELINE configs[4] shape on one GPU
+PMC_FILE_F32 = os.path.join("profiles", "r04_kernel_profile_bench720p_f32_mfma.json")  # the 720p frame with --operand-mode 0
 
 
 def load_kernel_profile(workload_is_default, pmc_file=None):
@@ -553,7 +554,9 @@ def main():
         prof.calibrate()
         # PMC / rocprofv3 profiles exist for the two BASELINE inference shapes (720p = configs[1], 1080p = the per-GPU shape of configs[4])
         pmc_file = {(720, 1280): PMC_FILE, (1080, 1920): PMC_FILE_1080P}.get((H, W))
-        pmc_ok = pmc_file is not None and (S, args.refine) == (1, 1)
+        if args.operand_mode == 0:                           # the f32-MFMA frame has its own stamped profile (720p only)
+            pmc_file = PMC_FILE_F32 if (H, W) == (720, 1280) else None
+        pmc_ok = pmc_file is not None and (S, args.refine) == (1, 1) and args.operand_mode in (0, 4)
         ktab, knote = load_kernel_profile(pmc_ok, pmc_file)
         prof.set_offsets(event_offsets(ktab))
         torch.cuda.synchronize()

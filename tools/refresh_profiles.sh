@@ -35,6 +35,9 @@ workload() {   # tag, stats csv name, out json name, command text, bench args...
 workload 720p ${ROUND}_rocprofv3_kernel_stats_bench720p.csv ${ROUND}_kernel_profile_bench720p.json \
   "bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train-leg --no-bf16-leg --no-f32-mfma-leg (720p, batch 1, operand mode 4)" \
   --steps 100 --warmup 10 --no-cpu-baseline --no-train-leg --no-bf16-leg --no-f32-mfma-leg || exit 1
+workload 720p_f32 ${ROUND}_rocprofv3_kernel_stats_bench720p_f32_mfma.csv ${ROUND}_kernel_profile_bench720p_f32_mfma.json \
+  "bench.py --operand-mode 0 --steps 100 --warmup 10 --no-cpu-baseline --no-train-leg --no-bf16-leg (720p, batch 1, exact f32 MFMA kernels)" \
+  --operand-mode 0 --steps 100 --warmup 10 --no-cpu-baseline --no-train-leg --no-bf16-leg || exit 1
 workload train ${ROUND}_rocprofv3_kernel_stats_train_b8.csv ${ROUND}_kernel_profile_train_b8.json \
   "bench.py --mode train --steps 10 --warmup 3 (8 pairs, 288x512)" \
   --mode train --steps 10 --warmup 3 || exit 1
@@ -44,6 +47,7 @@ workload 1080p ${ROUND}_rocprofv3_kernel_stats_bench1080p.csv ${ROUND}_kernel_pr
 
 cd $R
 python bench.py > $P/${ROUND}_bench_720p.json 2> $O/bench.err || exit 1
+python bench.py --operand-mode 0 --no-cpu-baseline --no-train-leg --no-bf16-leg > $P/${ROUND}_bench_720p_f32_mfma.json 2> $O/bench_f32.err || exit 1
 python bench.py --mode train > $P/${ROUND}_bench_train_1gpu.json 2> $O/train.err || exit 1
 python bench.py --height 1080 --width 1920 --no-cpu-baseline --no-train-leg --no-bf16-leg > $P/${ROUND}_bench_1080p.json 2> $O/bench1080.err || exit 1
 # multi-GPU readiness on ONE GPU: the same training step through a one-rank RCCL group (5 collectives + stream joins per step), next to
