@@ -106,3 +106,31 @@ def test_weight_image_is_an_exact_three_term_split(cuda):
             assert np.float32(np.float32(l + m) + h) == w[n_, 0, 0, k], (n_, k)
     # rows of the ragged second tile beyond Cout are zero
     assert not raw[1, :, 1].any()
+
+
+@pytest.mark.parametrize("k,Cin,Cout", [(1, 512, 128), (3, 128, 64), (1, 2048, 64)])
+def test_packed_error_against_float64_is_the_f32_mfma_error(cuda, k, Cin, Cout):
+    """Not a reduced-precision mode: against a FLOAT64 convolution of the same float32 inputs, the packed split kernel's error is
+    the exact-f32-MFMA kernel's error (both are float32 accumulations of exact -- resp. 2^-23-accurate -- products; the bf16-operand
+    mode on the same data is three orders of magnitude further away)."""
+    from stabnet_amd import ops
+    rng = np.random.default_rng(k * 1000 + Cin)
+    N, H, W = 1, 24, 32
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float32)
+    pad = k // 2
+    xp = np.pad(x.astype(np.float64), ((0, 0), (pad, pad), (pad, pad), (0, 0)))
+    cols = np.concatenate([xp[:, i:i + H, j:j + W, :] for i in range(k) for j in range(k)], axis=-1)      # [N,H,W,k*k*Cin] (kh, kw, c)
+    want = cols.reshape(-1, k * k * Cin) @ w.astype(np.float64).reshape(k * k * Cin, Cout)
+    want = want.reshape(N, H, W, Cout)
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(cuda)
+    wt = t(ops.pack_conv_weight(w))
+    got_p = ops.conv2d_packed(t(x), wt, pad=pad).cpu().numpy().astype(np.float64)
+    got_f = ops.conv2d(t(x), wt, pad=pad).cpu().numpy().astype(np.float64)
+    scale = np.abs(want).max()
+    e_p, e_f = np.abs(got_p - want).max() / scale, np.abs(got_f - want).max() / scale
+    r_p, r_f = np.sqrt(np.mean((got_p - want) ** 2)) / scale, np.sqrt(np.mean((got_f - want) ** 2)) / scale
+    print("k=%d K=%d: max / rms error vs float64, relative to the output scale: packed split %.2e / %.2e, f32 MFMA %.2e / %.2e" % (
+        k, k * k * Cin, e_p, r_p, e_f, r_f))
+    assert e_p <= 2.0 * e_f + 1e-7 and r_p <= 1.5 * r_f + 2e-8
+    assert e_p < 3e-6
