@@ -69,7 +69,8 @@ int conv_reduce_launches(const ConvArgs& a, int operand_mode = 0);      // (oper
 // register-staged launch (anything else: launch the towers one after the other).
 struct ConvPair { int m_tower, x_tower_floats /* N*H*W*Cin of one tower's input */; long dx, dy, dres, dscale; };
 bool conv_pair_supported(const ConvArgs& a);
-int conv_launch_pair(const ConvArgs& a, const ConvPair& pr, hipStream_t st, Prof* prof = nullptr);
+int conv_launch_pair(const ConvArgs& a, const ConvPair& pr, hipStream_t st, Prof* prof = nullptr,
+                     const float* w_img = nullptr /* pre-split image of a.w: the prologue-carrying 1x1 pairs run the packed split kernel */);
 
 // A bottleneck unit's 3x3 `conv2` and 1x1 `conv3` as ONE launch (conv_b2b_kernel.h): c2 / c3 are the two planned convolutions as
 // conv_launch() would take them (c2.out_scale / out_shift = the folded BN between them, ReLU implied; c2.y is not written).

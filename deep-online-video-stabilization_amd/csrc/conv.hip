@@ -545,8 +545,8 @@ int conv_launch(const ConvArgs& a_in, hipStream_t st, Prof* prof, int bf16_opera
     // packed split kernel with the fragment prologue: 1x1 / stride 1 layers that carry an input BN + ReLU (register-staged kernel or
     // the two-group PRO ring form otherwise); a K split goes through the slabs + reduce launch
     static const int packed_pro_on = env_int("STABNET_CONV_PACKED_PRO", 1);
-    const bool packed_pro = want_packed && packed_pro_on && !ring && t == T64x64 && bk32 && a.in_scale != nullptr && ring_pro_geometry(a, true) &&
-                            ring_pro_vectors_ok(a) && (a.splitk == 1 || a.partial != nullptr);
+    const bool packed_pro = want_packed && packed_pro_on && !ring && t == T64x64 && bk32 && a.in_scale != nullptr && a.out_floor == nullptr &&
+                            ring_pro_geometry(a, true) && ring_pro_vectors_ok(a) && (a.splitk == 1 || a.partial != nullptr);   // (out_floor: the kernel's pair distance)
     if (packed_pro) kg = 1;
     const bool packed = (want_packed && ring && kg == 1 && !pro && a.K % 32 == 0) || packed_pro;
     // a two-way K split runs inside the workgroup (no slabs, no reduce launch)
@@ -622,7 +622,25 @@ static int launch_pair_one(const ConvArgs& a, const ConvPair& pr, hipStream_t st
     return STABNET_OK;
 }
 
-int conv_launch_pair(const ConvArgs& a, const ConvPair& pr, hipStream_t st, Prof* prof) {
+// The packed split kernel's prologue form over the PAIR of towers (training forward, opt-in): launch_ring_pro with a weight image.
+static int launch_ring_packed_pro_pair(ConvArgs a, long delta, const float* w_img, hipStream_t st) {
+    const int cus = device_cus();
+    if (cus <= 0) {
+        stabnet_set_error("conv: cannot read the CU count");
+        return STABNET_ERR_LAUNCH;
+    }
+    a.w = w_img;
+    a.out_floor = reinterpret_cast<const float*>((size_t)delta);      // the kernel's pair distance (conv_ring_kernel.h PRO)
+    static const int per_cu = env_int("STABNET_CONV_PACKED_WGS_PER_CU", 2);
+    const long ntiles = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64) * a.splitk;
+    const int grid = (int)std::min<long>(ntiles, (long)per_cu * usable_cus(cus));
+    if (conv_packed_variant() == 5) conv_ring_f32_kernel<0, 5, 1, 1><<<grid, 256, 0, st>>>(a);
+    else conv_ring_f32_kernel<0, 4, 1, 1><<<grid, 256, 0, st>>>(a);
+    SN_LAUNCH_CHECK("conv_ring_f32_kernel<packed, PRO, pair>");
+    return STABNET_OK;
+}
+
+int conv_launch_pair(const ConvArgs& a, const ConvPair& pr, hipStream_t st, Prof* prof, const float* w_img) {
     g_bf16_operands = 0;
     SN_REQUIRE(a.Cin % 16 == 0 && a.Cout % 4 == 0, "conv pair: Cin %% 16 and Cout %% 4 must be 0");
     SN_REQUIRE(a.splitk >= 1 && a.steps_per_split >= 1 && a.div_hw_mul != 0, "conv pair: conv_plan() not called");
@@ -638,10 +656,12 @@ int conv_launch_pair(const ConvArgs& a, const ConvPair& pr, hipStream_t st, Prof
     // the second tower all derive from the distance of the two workspaces, which must be what ConvPair describes)
     const bool pro = bk32 && ring_pro_eligible(a) && pr.dx == pr.dscale - (long)pr.m_tower * a.Cin && pr.dy == pr.dscale - (long)pr.m_tower * a.Cout &&
                      (a.residual == nullptr || pr.dres == pr.dscale - (long)(a.N / 2) * a.res_H * a.res_W * a.res_ld);
-    if (pro) rc = launch_ring_pro(a, pr.dscale, st);
+    const bool packed = pro && w_img != nullptr && a.K % 32 == 0 && a.splitk == 1;
+    if (packed) rc = launch_ring_packed_pro_pair(a, pr.dscale, w_img, st);
+    else if (pro) rc = launch_ring_pro(a, pr.dscale, st);
     else if (bk32) rc = mode == 0 ? launch_pair_one<32, 0>(a, pr, st) : launch_pair_one<32, 1>(a, pr, st);
     else rc = mode == 0 ? launch_pair_one<16, 0>(a, pr, st) : launch_pair_one<16, 1>(a, pr, st);
-    if (rec) prof->end(st, pro ? PK_KERNEL_CONV_KG + 2 : PK_KERNEL_CONV_PAIR + mode * 2 + (bk32 ? 1 : 0), 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
+    if (rec) prof->end(st, packed ? PK_KERNEL_CONV_PACKED + 3 : pro ? PK_KERNEL_CONV_KG + 2 : PK_KERNEL_CONV_PAIR + mode * 2 + (bk32 ? 1 : 0), 2.0 * a.M * (double)(a.KH * a.KW * (a.cin_real ? a.cin_real : a.Cin)) * a.Cout,
                        4.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.K * a.Cout + (double)a.M * a.Cout * a.splitk),
                        a.M, a.Cout, a.K, a.splitk);
     if (rc) return rc;

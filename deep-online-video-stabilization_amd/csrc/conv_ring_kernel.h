@@ -112,9 +112,10 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
 
     // PRO: the pair of towers (see the header comment)
     // (KG > 1 with PRO -- the inference conv1 layers that split K -- is one tower and out_floor is an ordinary floor vector)
-    // (the packed split form -- inference conv1 layers -- is one tower as well)
-    const long pair_delta = (PRO && KG == 1 && !PK) ? (long)(size_t)p.out_floor : 0L;
-    const int m_tower = (PRO && KG == 1 && !PK && pair_delta != 0) ? (p.M >> 1) : 0x7fffffff;
+    // (the packed split form runs both: the inference conv1 layers -- one tower, out_floor null, so the distance is 0 -- and the
+    //  training forward's pairs)
+    const long pair_delta = (PRO && KG == 1) ? (long)(size_t)p.out_floor : 0L;
+    const int m_tower = (PRO && KG == 1 && pair_delta != 0) ? (p.M >> 1) : 0x7fffffff;
     const unsigned sc_base = (KG > 1) ? (unsigned)(size_t)(sn_lds_ptr_t)ring + (unsigned)(KG * GROUP_FLOATS * 4) + (unsigned)grp * (unsigned)(SC_FLOATS * 4)
                                       : lds_base + (unsigned)(GROUP_FLOATS * 4);   // [slot][wave][scale 32 | shift 32]
     // consumer steps of this workgroup (every slice has steps_per_split steps except the last one)
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(256 * KG) void conv_ring_f32_kernel(const ConvArgs 
                     conv_epilogue<1, 1, true>(acc, p, c_m0 + wm * 32, c_n0 + wn * 32, lane, 0,
                                               lds_base + (unsigned)(OFF + wave * SN_EPI_WAVE_BYTES));
                 }
-            } else if constexpr (PRO && !PK)
+            } else if constexpr (PRO)
             conv_epilogue<1, 1, false, true>(acc, p, c_m0 + wm * 32, c_n0 + wn * 32, lane, c_z,
                                              lds_base + (unsigned)(OFF + wave * SN_EPI_WAVE_BYTES), c_yoff, c_roff);
             else

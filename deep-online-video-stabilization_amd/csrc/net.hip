@@ -119,6 +119,8 @@ struct Net {
     PackTable packs{};                            // dgrad weight re-pack of every unit conv (training)
     int train_split = 0;                          // training plans: dgrad through the packed split kernels (stabnet_net_set_bf16_operands(net, 4))
     WeightImageTable dimg{};                      // ... pre-split images of the re-packed dgrad weights, one launch per step
+    WeightImageTable fimg{};                      // ... and of the forward weights (Step::wimg_off inside this region)
+    size_t fimg_floats = 0;
     long dimg_of_pack[56];                        // image offset of pack entry i (-1: K not a multiple of 32)
     size_t dimg_floats = 0;
     long pack_w3[16] = {0}, pack_w2[16] = {0}, pack_w1[16] = {0}, pack_sc[16] = {0};   // wt offsets per unit                     // re-laid-out stem weights [64][7][roundup(7*in_ch, 32)] behind the folded BN
@@ -511,6 +513,15 @@ static Net* build_net(int N, int H, int W, int in_ch, int n_theta, int keep_all)
                           (long)st_.conv_pair.N * (st_.conv.H + 2 * st_.conv.pad) * (st_.conv.W + 2 * st_.conv.pad) * st_.conv.Cin < (1L << 30) &&
                           (long)st_.conv_pair.M * st_.conv.Cout < (1L << 30);
             if (st_.pair_ok) net->splitk_bytes = std::max(net->splitk_bytes, bytes);
+        }
+    }
+    if (net->keep_all) {   // training plans: images of the forward weights, re-split once per step when the plan runs in split mode
+        net->fimg.n = 0;
+        for (Step& st_ : net->steps) {
+            if (st_.kind != S_CONV || st_.conv.K % 32 != 0 || st_.conv.rowrun || net->fimg.n >= 64) continue;
+            st_.wimg_off = (long)net->fimg_floats;
+            weight_image_table_add(net->fimg, st_.w_off, st_.wimg_off, st_.conv.Cout, st_.conv.K);
+            net->fimg_floats += conv_weight_image_floats(st_.conv.Cout, st_.conv.K);
         }
     }
     if (!net->keep_all) {  // pre-split weight images for the packed split kernel (stabnet_net_set_bf16_operands(net, 4))
@@ -998,7 +1009,7 @@ int stabnet_deploy_frame(const void* netp, const float* params, const float* fol
 // train_bundle_nobm.py:155-160).  The plan must have been created with keep_activations = 1.
 // =========================================================================================================
 struct TrainLayout {
-    size_t bn_scale, bn_shift, bn_mean, bn_invstd, GA, GB, T1, T2, T3, fcg0, fcg1, partial, fcpart, coef, wt, wt_img, argmax, splitk, slabs, total;
+    size_t bn_scale, bn_shift, bn_mean, bn_invstd, GA, GB, T1, T2, T3, fcg0, fcg1, partial, fcpart, coef, wt, wt_img, fw_img, argmax, splitk, slabs, total;
     size_t fcx[4];                  // FC head inputs of the PAIR ([2N, dims[k]], tower 1's rows behind tower 0's), in tower 0's workspace
     size_t fcpart_floats;
     size_t splitk_bytes, slab_floats;
@@ -1058,6 +1069,7 @@ static TrainLayout train_layout(const Net* net) {
     L.coef = take(3 * std::max<size_t>(net->max_c, 2048));
     L.wt = take((size_t)net->packs.prefix[net->packs.n]);
     L.wt_img = take(net->train_split ? net->dimg_floats : 0);
+    L.fw_img = take(net->train_split ? net->fimg_floats : 0);
     L.argmax = take((net->t_pool.size + 3) / 4);              // one byte per pooled element
     size_t sk = net->splitk_bytes;
     for (const UnitInfo& u : net->units) {
@@ -1097,6 +1109,10 @@ static int run_forward_train(const Net* net, float* params, int T, const float* 
     float* splitk = ws[0] + L.splitk;
     float* partial = ws[0] + L.partial;
     static const bool pair_convs = getenv("STABNET_TRAIN_PAIR_FWD") == nullptr || atoi(getenv("STABNET_TRAIN_PAIR_FWD")) != 0;   // debug switch
+    if (net->train_split) {                                // images of this step's forward weights: one launch, read by both towers
+        const int rc0 = launch_weight_split_images(params, ws[0] + L.fw_img, net->fimg, st);
+        if (rc0) return rc0;
+    }
     std::vector<char> have(net->bns.size(), 0);
     auto need_bn = [&](long chan_off) -> int {
         const BnInfo* b = find_bn(net, chan_off);
@@ -1142,6 +1158,8 @@ static int run_forward_train(const Net* net, float* params, int T, const float* 
                     a.in_scale = s.bn_off >= 0 ? scale + s.bn_off : nullptr;
                     a.in_shift = s.bn_off >= 0 ? shift + s.bn_off : nullptr;
                     a.partial = splitk;
+                    // split mode: the prologue-carrying 1x1 layers read the image of this step's weights (both towers, pair or not)
+                    const float* wimg = (net->train_split && s.wimg_off >= 0 && a.KH == 1 && a.in_scale != nullptr) ? ws[0] + L.fw_img + s.wimg_off : nullptr;
                     if (pair) {
                         // tower 1's tensors sit at the same offsets of ITS workspace: one element offset for everything, minus the
                         // N images (or tower rows) the pair's row index has already advanced by
@@ -1154,9 +1172,9 @@ static int run_forward_train(const Net* net, float* params, int T, const float* 
                         pr.dy = delta - (long)c.M * c.Cout;
                         pr.dres = delta - (long)c.N * c.res_H * c.res_W * c.res_ld;
                         pr.dscale = delta;
-                        rc = conv_launch_pair(a, pr, st, prof);
+                        rc = conv_launch_pair(a, pr, st, prof, wimg);
                     } else {
-                        rc = conv_launch(a, st, prof);
+                        rc = conv_launch(a, st, prof, wimg != nullptr ? 4 : 0, wimg);
                     }
                     break;
                 }

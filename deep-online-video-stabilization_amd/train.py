@@ -55,15 +55,17 @@ class Trainer:
         if self.device.type != "cuda":
             raise _lib.StabnetError("Trainer needs a GPU device; there is no CPU fallback")
         self.plan = NetPlan(N, H, W, cfg, keep_activations=True)
-        # split_operands: the dgrad launches of the backward run the packed split kernels (float32 operands as exact sums of three
-        # bf16 terms on the bf16 matrix pipe, f32 accumulate: include/stabnet_hip.h, operand mode 4) on an image of the re-packed
-        # weights written once per step.  None = the STABNET_TRAIN_SPLIT environment switch, default OFF: measured at 8 pairs /
-        # 288x512 the converted dgrad launches are 18-24 % faster (49.4 -> 40.7 us, 103.1 -> 78.2 us: -0.61 ms per step) but every
-        # f32-MFMA launch beside them runs 3-6 % slower (the chip is power-limited and the forward / wgrad launches -- 80 % of the
-        # matrix time -- cannot read a weight image or are not converted yet): 528 -> 518 pairs/s.
+        # split_operands: the launches of the step whose B operand is a weight tensor -- the prologue-carrying 1x1 forward pairs and
+        # the stride-1 dgrad launches -- run the packed split kernels (float32 operands as exact sums of three bf16 terms on the bf16
+        # matrix pipe, f32 accumulate: include/stabnet_hip.h, operand mode 4) on images of the forward weights and of the re-packed
+        # dgrad weights written once per step (two launches).  None = the STABNET_TRAIN_SPLIT environment switch, default ON:
+        # measured at 8 pairs / 288x512, 527 -> 540 pairs/s (the dgrad half alone LOSES 2 %: converted launches 18-24 % faster, but
+        # every f32-MFMA launch beside them 3-6 % slower -- the chip is power-limited; with the forward pairs converted as well the
+        # balance turns).  wgrad multiplies two activations and the 3x3 forward pairs need the padding mask behind the prologue:
+        # both stay on the f32 MFMA kernels.
         if split_operands is None:
             import os
-            split_operands = os.environ.get("STABNET_TRAIN_SPLIT", "0") == "1"
+            split_operands = os.environ.get("STABNET_TRAIN_SPLIT", "1") != "0"
         self.split_operands = bool(split_operands)
         if self.split_operands:
             _lib.call("stabnet_net_set_bf16_operands", self.plan.handle, 4)

@@ -1,7 +1,7 @@
-"""GPU: the training backward with its dgrad launches on the packed split kernels (Trainer(split_operands=True); opt-in:
+"""GPU: the training step with its weight-operand launches on the packed split kernels (Trainer(split_operands=True), the default:
 float32 operands as exact sums of three bf16 terms on the bf16 matrix pipe, an image of the re-packed dgrad weights written once
-per step) against the same step on the exact-f32-MFMA kernels (split_operands=False).  The forward is the same code, so the
-losses are bit-identical; the gradients differ by float32 summation order only."""
+per step, and its prologue-carrying 1x1 forward pairs likewise) against the same step on the exact-f32-MFMA kernels
+(split_operands=False): float32 summation order is all that differs."""
 import os
 import sys
 
@@ -40,20 +40,24 @@ def test_split_dgrad_step_equals_f32_mfma_step(cuda, N, H, W):
         torch.cuda.empty_cache()
     g0, l0, plan, n0 = res[False]
     g1, l1, _, n1 = res[True]
-    assert n0 == 0 and n1 >= 30, (n0, n1)                       # the mode is really on: the stride-1 dgrad launches of the 16 units
-    assert l0["total_loss"] == l1["total_loss"]                  # same forward
-    # per parameter tensor: difference relative to the tensor's own gradient scale
-    worst = 0.0
+    assert n0 == 0 and n1 >= 60, (n0, n1)                       # the mode is really on: the stride-1 dgrad launches and the 1x1 forward pairs
+    assert l1["total_loss"] == pytest.approx(l0["total_loss"], rel=1e-5)
+    # per parameter tensor: difference relative to the tensor's own gradient scale.  The forward's activations move in the 7th digit,
+    # so a ReLU / arg-max decision can fall the other way (tests/test_train_gpu.py): single elements may then differ by per cents of
+    # their tensor's scale, whole tensors by ~1e-3 -- the bars of the un-forced comparison there.
+    worst_el, worst_l2 = 0.0, 0.0
     for name, off, kind, dims, aux in plan.table:
         n = int(np.prod(dims))
         if n == 0 or off + n > g0.size:
             continue
-        a, c = g0[off:off + n], g1[off:off + n]
-        s = np.abs(a).max()
-        if s > 0:
-            worst = max(worst, float(np.abs(a - c).max() / s))
-    print("worst per-tensor relative gradient difference, split dgrad vs f32 MFMA dgrad: %.3e" % worst)
-    assert worst < 2e-4
+        a, c = g0[off:off + n].astype(np.float64), g1[off:off + n].astype(np.float64)
+        sc = np.abs(a).max()
+        if sc > 0:
+            worst_el = max(worst_el, float(np.abs(a - c).max() / sc))
+            worst_l2 = max(worst_l2, float(np.linalg.norm(a - c) / max(np.linalg.norm(a), 1e-30)))
+    whole = float(np.linalg.norm(g0.astype(np.float64) - g1) / np.linalg.norm(g0.astype(np.float64)))
+    print("split step vs f32 MFMA step: worst element %.3e, worst tensor L2 %.3e, whole gradient L2 %.3e" % (worst_el, worst_l2, whole))
+    assert worst_el < 1e-1 and worst_l2 < 2e-2 and whole < 5e-3
     # and the run is reproducible bit for bit
     tr = Trainer(P, N, H, W, cfg, device=cuda, split_operands=True)
     tr.forward_backward(b, gates, apply_update=False)
