@@ -581,7 +581,7 @@ static int run_forward(const Net* net, const float* params, const float* fold, c
                 }
                 a.partial = splitk;
                 rc = conv_launch(a, st, prof, net->bf16_operands,
-                                 (net->bf16_operands == 4 && s.wimg_off >= 0) ? fold + 2 * net->G + net->stem_w_floats + net->merge_floats + s.wimg_off : nullptr);
+                                 (net->bf16_operands == 4 && s.wimg_off >= 0 && !net->keep_all) ? fold + 2 * net->G + net->stem_w_floats + net->merge_floats + s.wimg_off : nullptr);
                 break;
             }
             case S_CONV_B2B: {
@@ -871,10 +871,13 @@ int stabnet_net_fold_bn(const void* netp, const float* params, float* fold, floa
         rc = launch_stem_repack(params + net->w_stem, fold + 2 * net->G, 64, 7, 7, net->in_ch_pad, net->in_ch, (hipStream_t)stream);
         if (rc) return rc;
     }
-    // pre-split weight images (inference plans): from the weights each launch reads
+    // pre-split weight images (inference plans ONLY: a training plan's Step::wimg_off points into its own workspace region, and its
+    // `fold` has no image region): from the weights each launch reads
+    if (net->keep_all) return STABNET_OK;
     float* img = fold + 2 * net->G + net->stem_w_floats + net->merge_floats;
     for (const Step& s : net->steps) {
         if (s.kind != S_CONV || s.wimg_off < 0) continue;
+        SN_REQUIRE((size_t)s.wimg_off + conv_weight_image_floats(s.conv.Cout, s.conv.K) <= net->wimg_floats, "fold_bn: weight image outside the fold buffer");
         const float* w = s.conv.rowrun ? fold + 2 * net->G : params + s.w_off;
         rc = launch_weight_split_image(w, s.conv.Cout, s.conv.K, img + s.wimg_off, (hipStream_t)stream);
         if (rc) return rc;
