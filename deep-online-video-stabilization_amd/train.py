@@ -58,14 +58,15 @@ class Trainer:
         # split_operands: the launches of the step whose B operand is a weight tensor -- the prologue-carrying 1x1 forward pairs and
         # the stride-1 dgrad launches -- run the packed split kernels (float32 operands as exact sums of three bf16 terms on the bf16
         # matrix pipe, f32 accumulate: include/stabnet_hip.h, operand mode 4) on images of the forward weights and of the re-packed
-        # dgrad weights written once per step (two launches).  None = the STABNET_TRAIN_SPLIT environment switch, default ON:
-        # measured at 8 pairs / 288x512, 527 -> 540 pairs/s (the dgrad half alone LOSES 2 %: converted launches 18-24 % faster, but
-        # every f32-MFMA launch beside them 3-6 % slower -- the chip is power-limited; with the forward pairs converted as well the
-        # balance turns).  wgrad multiplies two activations and the 3x3 forward pairs need the padding mask behind the prologue:
-        # both stay on the f32 MFMA kernels.
+        # dgrad weights written once per step (two launches).  None = the STABNET_TRAIN_SPLIT environment switch, default OFF.
+        # Measured at 8 pairs / 288x512: the converted launches are 10-24 % faster (1x1 forward pairs 57.7 ->
+        # 51.9 us, dgrad 49.7 -> 38.7 us and 104.0 -> 77.9 us: -1.0 ms of 15.2 per step) and a 10-step run shows 527 -> 540
+        # pairs/s -- but over 200 steps it is 526.1 against 527.2: the chip is power-limited, and once the clocks settle every
+        # f32-MFMA launch beside the packed ones (wgrad, the 3x3 forward pairs: 60 % of the matrix time, neither can read a weight
+        # image) runs 4-8 % slower.  It pays at larger batches (16 / 32 / 64 pairs per GPU: +2 / +3 / +6 %).
         if split_operands is None:
             import os
-            split_operands = os.environ.get("STABNET_TRAIN_SPLIT", "1") != "0"
+            split_operands = os.environ.get("STABNET_TRAIN_SPLIT", "0") == "1"
         self.split_operands = bool(split_operands)
         if self.split_operands:
             _lib.call("stabnet_net_set_bf16_operands", self.plan.handle, 4)

@@ -1,4 +1,4 @@
-"""GPU: the training step with its weight-operand launches on the packed split kernels (Trainer(split_operands=True), the default:
+"""GPU: the training step with its weight-operand launches on the packed split kernels (Trainer(split_operands=True); opt-in:
 float32 operands as exact sums of three bf16 terms on the bf16 matrix pipe, an image of the re-packed dgrad weights written once
 per step, and its prologue-carrying 1x1 forward pairs likewise) against the same step on the exact-f32-MFMA kernels
 (split_operands=False): float32 summation order is all that differs."""
