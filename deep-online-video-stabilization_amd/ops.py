@@ -54,8 +54,10 @@ def conv2d_packed(x, w_ohwi, bias=None, in_scale=None, in_shift=None, residual=N
     Wo = (W + 2 * pad - KW) // stride + 1
     y = empty((N, Ho, Wo, Cout), x)
     L = _lib.lib()
-    img = torch.empty(max(int(L.stabnet_conv_weight_image_floats(Cout, KH, KW, Cin)), 1), dtype=torch.float32, device=x.device)
-    _lib.call("stabnet_conv_weight_split_image", ptr(w), Cout, KH, KW, Cin, ptr(img), stream_ptr(x.device), device=x.device)
+    n_img = int(L.stabnet_conv_weight_image_floats(Cout, KH, KW, Cin))
+    img = torch.empty(max(n_img, 1), dtype=torch.float32, device=x.device)
+    if n_img > 0:                      # (Cin not a multiple of 32: no image exists and the call runs the exact-f32 kernels on w_ohwi)
+        _lib.call("stabnet_conv_weight_split_image", ptr(w), Cout, KH, KW, Cin, ptr(img), stream_ptr(x.device), device=x.device)
     ws_bytes = max(int(L.stabnet_conv2d_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)), max(splitk, 0) * N * Ho * Wo * Cout * 4)
     ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=x.device)
     rH, rW = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)

@@ -36,6 +36,9 @@ CASES = [
     (1, 60, 60, 1024, 256, 1, 1, 0, True, False, 0, True, 2),   # block-3 conv1: prologue + two K groups inside the workgroup
     (1, 23, 40, 2048, 512, 1, 1, 0, True, False, 0, True, 4),   # block-4 conv1: prologue + slabs
     (1, 17, 23, 128, 96, 1, 1, 0, True, True, 0, False, 2),     # prologue, two groups, ragged tiles
+    # geometries the packed kernels do not take: the same call runs the exact-f32 kernels on w_ohwi
+    (1, 20, 24, 16, 64, 7, 2, 3, False, True, 0, False, 0),     # Cin = 16 (no weight image exists)
+    (1, 37, 63, 128, 128, 3, 2, 1, True, False, 0, False, 0),   # 3x3 with a prologue (register-staged kernel)
 ]
 
 
