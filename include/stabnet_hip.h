@@ -138,7 +138,11 @@ void stabnet_net_destroy(void* net);
  *      results (theta within 2e-7 of the oracle, like mode 0) on the 16x faster matrix pipe; VALU-bound, slower than mode 0: kept
  *      as the reference form of mode 4;
  *   4  packed split: the weights are split once into a fragment-major image inside `fold` (stabnet_net_fold_bn), only the A
- *      fragments are split at run time (conv_ring_f32_kernel<MODE, 4, KG, PRO>).  Same f32-level parity bar as mode 0. */
+ *      fragments are split at run time (conv_ring_f32_kernel<MODE, 4, KG, PRO>).  Same f32-level parity bar as mode 0.
+ * Training plans (keep_activations = 1) accept 0 and 4 only; 4 = the step's weight-operand launches (the prologue-carrying 1x1
+ * forward pairs, the stride-1 dgrad launches) read images of the forward weights and of the re-packed dgrad weights that the step
+ * writes itself, inside its workspace -- call it BEFORE stabnet_net_train_workspace_bytes().  Off by default in the Python
+ * mirror (no sustained gain at 8 pairs per GPU on a power-limited part; it pays at larger batches). */
 int stabnet_net_set_bf16_operands(void* net, int on);
 int stabnet_net_num_params(const void* net);
 int stabnet_net_param_info(const void* net, int idx, char* name, int name_cap, long* offset, int* kind, int* dims4,
