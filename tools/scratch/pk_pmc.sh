@@ -1,4 +1,8 @@
 #!/bin/bash
+# build the probes first (on the build host; tools/bin/ is git-ignored but travels with gpurun):
+#   for ab in 0 1 4 8 32 40 41 45; do hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -Wno-inline-asm -Wno-unused-function \
+#       -DPROBE_BF16=4 -DRING_ABLATE=$ab -I deep-online-video-stabilization_amd/csrc -o tools/bin/ring_probe_pk_$ab tools/ring_probe.hip; done
+#   (-DPROBE_BF16=0 -> tools/bin/ring_probe_f32_0, -DPROBE_BF16=5 -> tools/bin/ring_probe_ps_<ablate>)
 # SQ counters of the packed split kernel next to the f32-MFMA kernel (stand-alone launches of the stem and block-2 3x3 geometries)
 export TMPDIR=/tmp
 R=$PWD
