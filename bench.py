@@ -654,9 +654,13 @@ def main():
                       "stabilized frames/sec (%dx%d)" % (W, H),
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.operand_mode == 0 else "f32 (conv operands as exact sums of 3 bf16 terms, %d bf16 partial products per "
-                     "product on v_mfma_f32_32x32x16_bf16, f32 accumulate: f32-level results, tests/test_operand_mode4_gpu.py)" % (
-                         9 if args.operand_mode == 3 else 6),
+            # operands, results and accumulation are float32 in every headline mode; mode 4 multiplies them as exact 3 x bf16 splits
+            "dtype": "f32" if args.operand_mode == 0 else "f32 (bf16x3 split MFMA, f32 accumulate)",
+            "arithmetic": "exact f32 MFMA (v_mfma_f32_32x32x2_f32)" if args.operand_mode == 0 else
+                          "every f32 conv operand is the exact sum of 3 bf16 terms; %d bf16 x bf16 partial products per f32 product on "
+                          "v_mfma_f32_32x32x16_bf16, f32 accumulate; f32-level results (theta 1e-7 from the oracle, error against a float64 "
+                          "convolution = the f32 MFMA kernels': tests/test_operand_mode4_gpu.py, tests/test_conv_packed_gpu.py)" % (
+                              9 if args.operand_mode == 3 else 6),
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: v2_93 net, %dx%d, %d stream(s)/GPU, batch=1 per stream, "
                                    "13-ch stack from a 32-deep ring (lags 1,2,4,8,16,32; --before-ch %d ignored as in "
